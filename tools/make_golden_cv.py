@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Extract the cross-validation known-answer fixture from the reference's own
+artifacts into tests/golden/cv/ (data only: inputs and expected outputs).
+
+Source (read-only, /root/reference/sac/cross_validation):
+  in_files/bosonic_delta_peak/t_{rep}{a,b}.in            -- t.in inputs
+  out_files/bosonic_delta_peak/{rep}{a,b}/free/GSAC.csv  -- G_SAC(tau) per Theta (cv:105-108)
+  out_files/bosonic_delta_peak/chi2/free_v.csv           -- expected output of calc_cv.jl:82-107
+                                                            (row 1 = Theta, row 1+rep = chi2_v/N_tau)
+Run once in the build container; the outputs are committed.
+"""
+import os, shutil, sys
+
+REF = "/root/reference/sac/cross_validation"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "cv")
+REPS = [1, 2]
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for rep in REPS:
+        for half in "ab":
+            shutil.copyfile(f"{REF}/in_files/bosonic_delta_peak/t_{rep:03d}{half}.in",
+                            f"{OUT}/t_{rep:03d}{half}.in")
+            shutil.copyfile(f"{REF}/out_files/bosonic_delta_peak/{rep:03d}{half}/free/GSAC.csv",
+                            f"{OUT}/GSAC_free_{rep:03d}{half}.csv")
+    with open(f"{REF}/out_files/bosonic_delta_peak/chi2/free_v.csv") as f:
+        rows = f.read().splitlines()
+    with open(f"{OUT}/free_v_expected.csv", "w") as f:
+        f.write(rows[0] + "\n")
+        for rep in REPS:
+            f.write(rows[rep] + "\n")
+    # one committed reference run (statistical oracle): anneal curve + its parameters
+    run = f"{REF}/out_files/bosonic_delta_peak/001a/free"
+    for name in ("anneal.csv", "accept_rate.csv", "in_free.in"):
+        shutil.copyfile(f"{run}/{name}", f"{OUT}/run001a_free_{name}")
+    os.system(f"chmod -R u+w {OUT}")
+
+if __name__ == "__main__":
+    sys.exit(main())
