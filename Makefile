@@ -1,0 +1,21 @@
+# Builds libsac_hip.so (the product) for gfx950 and the CPU oracle (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+HIPFLAGS ?= -O3 -std=c++20 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -Wall -Wno-unused-value
+SRC = sac_amd/csrc/sac_hip.hip
+HDR = $(wildcard sac_amd/csrc/*.h) include/sac_hip.h
+
+all: sac_amd/libsac_hip.so oracle
+
+sac_amd/libsac_hip.so: $(SRC) $(HDR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
+
+asm: $(SRC) $(HDR)
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/sac_hip.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -f sac_amd/libsac_hip.so; rm -rf build; $(MAKE) -C oracle clean
+
+.PHONY: all oracle clean asm

@@ -1,0 +1,135 @@
+/*
+ * include/sac_hip.h -- C ABI of libsac_hip.so, the MI355X (gfx950) sampling engine for
+ * Stochastic Analytic Continuation.
+ *
+ * The reference (gabes135/sac, pure Julia) has no FFI: this header IS the drop-in boundary,
+ * cut where the reference's annealing routines call the fixed-Theta stages
+ * (SURVEY.md section 8b).  Each entry point names the reference call it replaces;
+ * "free:NNN" = /root/reference/sac/free/sac_free.jl line NNN.  INTEGRATION.md shows the
+ * `ccall` stubs a maintainer adds to sac_free.jl.
+ *
+ * Conventions: every function returns 0 on success or a negative SAC_E_* code and never
+ * exits or throws (replaces Julia `throw("Invalid Kernel type.")` free:195); the message of
+ * the calling thread's last failure is sac_last_error().  The caller owns all host buffers; the
+ * library copies in/out during the call.  A handle is bound to one GPU and is not thread safe.
+ * Arrays use the reference's element types: positions Int64 (absolute grid index omega_i),
+ * amplitudes/Gbar/K Float64.
+ *
+ * Semantic extension over the reference: n_chains independent Markov chains per handle
+ * (one wavefront each).  Chain c draws from the Philox4x32-10 stream keyed
+ * (seed, chain_offset + c); with n_chains = 1 the chain is, move for move, the one the CPU
+ * oracle (oracle/sac_oracle.c) produces for the same seed.
+ */
+#ifndef SAC_HIP_H
+#define SAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAC_OK            0
+#define SAC_E_INVALID    -1   /* bad argument / unsupported size */
+#define SAC_E_STATE      -2   /* call order (e.g. sampling before the problem is uploaded) */
+#define SAC_E_HIP        -3   /* HIP runtime error (message has the hipError string) */
+#define SAC_E_NOMEM      -4
+
+#define SAC_KIND_FREE     0   /* sac/free/sac_free.jl */
+
+#define SAC_HIST_REFERENCE  0 /* free:918 semantics: duplicate frequencies collapse, last delta wins */
+#define SAC_HIST_ACCUMULATE 1 /* every delta adds its amplitude */
+
+#define SAC_MAX_N_TAU   128
+#define SAC_MAX_N_OMEGA 2048
+
+typedef struct sac_handle sac_handle_t;
+
+typedef struct {
+    int32_t  kind;          /* SAC_KIND_* */
+    int32_t  par;           /* free:6-10: 1 equal amplitudes, 2 amplitude updates, 3 unequal fixed */
+    int32_t  symm;          /* free:71 */
+    int32_t  n_tau;         /* N_tau   (<= SAC_MAX_N_TAU) */
+    int32_t  n_omega;       /* N_omega: deltas per chain (3 .. SAC_MAX_N_OMEGA) */
+    int32_t  n_chains;      /* independent chains on this GPU */
+    int64_t  n_grid;        /* N_omega_i: columns of the K table (free:149,153) */
+    int64_t  wi_0;          /* omega_i_0 (free:140) */
+    int64_t  wi_m;          /* omega_i_m (free:141) */
+    uint64_t seed;          /* Philox key */
+    uint32_t chain_offset;  /* global id of chain 0 (shards chains across GPUs/ranks) */
+    int32_t  device;        /* HIP device ordinal */
+    int32_t  hist_mode;     /* SAC_HIST_* */
+    int32_t  hist_copies;   /* histogram replicas chains scatter into; 0 = auto.
+                               hist_copies == n_chains gives every chain a private replica
+                               (plain read-modify-write, bit-reproducible). */
+    int32_t  sweeps_per_launch; /* 0 = default; sweeps a single kernel launch runs */
+    int32_t  reserved;
+} sac_config_t;
+
+typedef struct {
+    double   sampled_chi2;     /* <chi^2>: mean over chains of the per-chain sweep average (free:919,925) */
+    double   chi2_min;         /* min over chains (free:315-317) */
+    double   accept_rates[6];  /* mean over chains (free:56; slot 2 counts 2 per accepted pair, free:389) */
+    double   windows[4];       /* mean over chains of update_windows (free:57) */
+    uint64_t proposals;        /* since creation, all chains */
+    uint64_t evaluated;        /* proposals that reached the chi^2 evaluation (in bounds) */
+    uint64_t accepted;         /* accepted proposals */
+    uint64_t accepted_moves;   /* accepted proposals weighted by deltas moved (1/2/3) */
+    uint64_t sweeps;           /* chain-sweeps since creation */
+    double   last_stage_ms;    /* device time of the last adjust_windows / sample call */
+    double   last_kernel_ms;   /* device time spent in the sweep kernel proper during it */
+    int64_t  last_kernel_launches;
+} sac_stats_t;
+
+typedef struct {
+    double  chi2_new;   /* chi^2 of the proposed configuration (0 when not evaluated) */
+    int32_t flags;      /* bit0 evaluated, bit1 accepted */
+    int32_t move;       /* 1 single, 2 pair, 3 triple, 4 A+omega, 5 pair-A */
+} sac_move_rec_t;
+
+const char *sac_last_error(void);
+
+/* SAC(...) constructor, sampler fields only (free:5-76, 1191-1199). */
+int sac_create(const sac_config_t *cfg, sac_handle_t **out);
+int sac_destroy(sac_handle_t *h);
+
+/* Hands over what read_G! and initialize! built on the host (free:99-131, 199-216):
+ * K[n_grid][n_tau] with tau contiguous (Julia's column-major K_array[n_tau, n_grid]), already in
+ * the covariance eigenbasis, G = U^T G and sigma_inv (free:123,110). */
+int sac_upload_problem(sac_handle_t *h, const double *K, const double *G, const double *sigma_inv);
+
+/* omega_i_array / A_array / update_windows of one chain (chain = -1: all chains).  NULL = keep.
+ * free:215, 1218, 1254. */
+int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, const double *A,
+                  const double *windows);
+int sac_get_state(sac_handle_t *h, int32_t chain, int64_t *wi, double *A, double *windows);
+
+/* Gbar = calc_Gbar; chi2 = calc_chi2; chi2_min = chi2 for every chain (free:1213-1216). */
+int sac_init_gbar(sac_handle_t *h);
+int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min);
+int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, double chi2, double chi2_min);
+
+/* adjust_windows(self, steps, theta)  free:866-899 */
+int sac_adjust_windows(sac_handle_t *h, int64_t steps, double theta);
+/* sample(self, steps, theta)          free:903-927 */
+int sac_sample(sac_handle_t *h, int64_t steps, double theta);
+
+/* self.sampled_chi2, chi2_min, accept_rates, update_windows after a stage (free:1064-1076). */
+int sac_get_stats(sac_handle_t *h, sac_stats_t *out);
+/* per-chain view: out6 = {sampled_chi2, chi2, chi2_min, sweeps, 0, 0}; accept_rates[6] */
+int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6, double *accept_rates);
+
+/* self.sampled_spec (free:59,918,924): mean over chains of the per-chain sweep average, n_grid doubles. */
+int sac_get_histogram(sac_handle_t *h, double *out);
+/* Same histogram as the un-normalised sum over this handle's chains, written to DEVICE memory
+ * (e.g. a tensor handed to an RCCL all-reduce); *steps_times_chains receives the divisor. */
+int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, double *steps_times_chains);
+
+/* Debug/parity: record every proposal of one chain (up to capacity) during the following stages. */
+int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);
+int sac_get_move_log(sac_handle_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,326 @@
+// sac/free fixed-Theta sweep on one wavefront per Markov chain (gfx950).
+//
+// Reference behaviour: /root/reference/sac/free/sac_free.jl ("free:NNN")
+//   single_w_move 274-324, double_w_move 328-397, triple_w_move 401-475, run_updates 825-861,
+//   adjust_windows 866-899 (window retune), sample 903-927 (histogram, <chi^2>).
+//
+// Mapping onto the wave:
+//   lane            = tau index (two per lane when 64 < N_tau <= 128); Gbar, G, sigma_inv live in
+//                     registers, chi^2 is one DPP tree reduction (wave_ops.h)
+//   LDS             = the chain's delta positions (relative grid index, uint32)
+//   proposal decode = lane-parallel: lane j draws and decodes proposal base+j of a group of 64
+//                     (Philox blocks, index, shift, bounds) with no serial dependency
+//   proposal resolve= sequential over the group (the Markov chain IS sequential); the K columns
+//                     of proposal j+DEPTH are in flight while proposal j is resolved.  An accepted
+//                     move that touches a delta used by a later, already decoded proposal re-decodes
+//                     that lane, and a prefetched column pair that no longer matches is re-fetched,
+//                     so the chain is exactly the sequential one.
+#pragma once
+#include "wave_ops.h"
+
+namespace sacdev {
+
+struct ChainScalars {
+    double chi2, chi2_min;
+    double windows[4];
+    double acc[6];              // accept_rates accumulators (free:56)
+    double sum_chi2;            // sampled_chi2 accumulator (free:919)
+    unsigned long long sweep;   // sweeps since creation (Philox counter word)
+    unsigned long long counters[4];   // proposals, evaluated, accepted, accepted delta-moves
+};
+
+struct MoveRec { double chi2_new; int flags; int move; };
+
+enum : int { STAGE_ZERO_ACC = 1, STAGE_SAMPLE = 2, STAGE_RETUNE = 4 };
+
+struct FreeParams {
+    const double *K;            // [n_grid][ntp], tau contiguous, zero padded
+    const double *G;            // [128] zero padded
+    const double *sinv;         // [128] zero padded
+    uint32_t *wi;               // [n_chains][wi_stride] relative positions
+    const double *A;            // [n_chains][wi_stride] amplitudes (used when !uniform_A)
+    double *gbar;               // [n_chains][128]
+    ChainScalars *sc;           // [n_chains]
+    double *hist;               // [hist_copies][n_grid]
+    MoveRec *log;
+    unsigned long long *log_len;
+    long long log_cap;
+    long long n_grid;
+    double A_uniform;
+    double inv2theta;
+    double retune_div;
+    int ntp, n_tau, n_omega, wi_stride;
+    int gmax;                   // wi_m - wi_0: largest relative position
+    int n_chains;
+    uint32_t chain_offset, seed_lo, seed_hi;
+    int uniform_A;
+    int hist_copies, hist_exclusive, hist_mode;
+    int n_sweeps, flags, par;
+    int log_chain;
+};
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAX_N_OMEGA = 2048;
+
+// Per-wave state that lives in registers for the whole launch.
+template <int NTL>
+struct Chain {
+    const double *K;
+    uint32_t *wi;               // LDS
+    int lane, ntp, n_omega, gmax;
+    int idx[NTL];               // this lane's tau slot(s), clamped into the padded column
+    double gbar[NTL], G[NTL], sinv[NTL];
+    double chi2, chi2_min, inv2theta;
+    uint32_t key0, key1, chain_id, sweep_lo, sweep_hi;
+    unsigned long long n_prop, n_eval, n_acc, n_accmoves;
+    // amplitudes
+    const double *A;            // this chain's amplitude array (global)
+    double A_uniform;
+    int uniform_A;
+    // move log
+    MoveRec *log;
+    long long log_cap;
+    unsigned long long log_pos;
+};
+
+template <int NTL>
+__device__ __forceinline__ void load_col(const Chain<NTL> &c, int col, double (&out)[NTL])
+{
+    const double *base = c.K + (size_t)(unsigned)col * (size_t)c.ntp;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) out[t] = base[c.idx[t]];
+}
+
+// One decoded proposal per lane.  NCOL deltas move: k = index, wold/wnew = relative positions.
+template <int NCOL>
+struct Decoded {
+    int k[NCOL], wold[NCOL], wnew[NCOL];
+    int sd;         // signed shift (single, pair)
+    int inb;        // proposal reaches the chi^2 evaluation
+    int dead;       // retry blocks exhausted: never evaluated
+    double uacc;
+    double A[NCOL];
+};
+
+template <int NCOL>
+__device__ __forceinline__ void compute_new(Decoded<NCOL> &d, int gmax)
+{
+    if constexpr (NCOL == 1) {
+        d.wnew[0] = d.wold[0] + d.sd;                               // free:287-291
+    } else if constexpr (NCOL == 2) {
+        d.wnew[0] = d.wold[0] + d.sd;                               // free:345-351
+        d.wnew[1] = d.wold[1] - d.sd;
+    } else {
+        const int dw = (d.wold[1] + d.wold[2] - 2 * d.wold[0]) / 3; // free:424 (truncating div)
+        d.wnew[0] = d.wold[0] + 2 * dw;
+        d.wnew[1] = d.wold[1] - dw;
+        d.wnew[2] = d.wold[2] - dw;
+    }
+    bool ok = !d.dead;
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) ok = ok && (d.wnew[c] >= 0) && (d.wnew[c] <= gmax);  // free:293-297
+    d.inb = ok ? 1 : 0;
+}
+
+// signed shift from the window draw: delta = 1 + floor(U * window)  (free:285)
+__device__ __forceinline__ int shift_from_draw(double u_mag, double u_sign, double window)
+{
+    const double f = __builtin_floor(u_mag * window);
+    const int mag = (f < 1.0e9) ? 1 + (int)f : (1 << 30);   // >= 2^30 is outside any grid
+    return (u_sign < 0.5) ? mag : -mag;
+}
+
+template <int NCOL, int NTL>
+__device__ __forceinline__ void decode(const Chain<NTL> &c, int move, uint32_t iter, double window,
+                                       Decoded<NCOL> &d)
+{
+    const uint32_t c2 = c.sweep_hi | ((uint32_t)move << 16);
+    const u32x4 b0 = philox4x32_10(iter, c.sweep_lo, c2, c.chain_id, c.key0, c.key1);
+    const u32x4 b1 = philox4x32_10(iter, c.sweep_lo, c2 | (1u << 24), c.chain_id, c.key0, c.key1);
+    const uint32_t n = (uint32_t)c.n_omega;
+    uint32_t retry = 2;
+    d.dead = 0;
+    d.sd = 0;
+    d.k[0] = index_from_word(b0.x, n);
+    if constexpr (NCOL >= 2) {
+        int k2 = index_from_word(b0.y, n);
+        while (k2 == d.k[0]) {                                      // free:339-341
+            if (retry > 255) { d.dead = 1; k2 = (d.k[0] + 1) % (int)n; break; }
+            const u32x4 br = philox4x32_10(iter, c.sweep_lo, c2 | (retry << 24), c.chain_id, c.key0, c.key1);
+            ++retry;
+            k2 = index_from_word(br.x, n);
+        }
+        d.k[1] = k2;
+    }
+    if constexpr (NCOL == 3) {
+        int k3 = index_from_word(b0.z, n);
+        while (k3 == d.k[0] || k3 == d.k[1]) {                      // free:418-420
+            if (retry > 255) { d.dead = 1; k3 = (d.k[0] + d.k[1] + 1) % (int)n; break; }
+            const u32x4 br = philox4x32_10(iter, c.sweep_lo, c2 | (retry << 24), c.chain_id, c.key0, c.key1);
+            ++retry;
+            k3 = index_from_word(br.y, n);
+        }
+        d.k[2] = k3;
+    }
+    if constexpr (NCOL == 1) {
+        d.sd = shift_from_draw(u01(b0.y, b0.z), u01(b0.w, b1.x), window);
+        d.uacc = u01(b1.y, b1.z);
+    } else if constexpr (NCOL == 2) {
+        d.sd = shift_from_draw(u01(b0.z, b0.w), u01(b1.x, b1.y), window);
+        d.uacc = u01(b1.z, b1.w);
+    } else {
+        d.uacc = u01(b0.w, b1.x);
+    }
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q) {
+        d.wold[q] = (int)c.wi[d.k[q]];
+        d.A[q] = c.uniform_A ? c.A_uniform : c.A[d.k[q]];
+    }
+    compute_new<NCOL>(d, c.gmax);
+}
+
+// A_c * (K[:, new] - K[:, old]) for every moved delta (free:301-302, 367-369, 448-451)
+template <int NCOL, int NTL>
+__device__ __forceinline__ void increments(const double (&A)[NCOL], const double (&kn)[NCOL][NTL],
+                                           const double (&ko)[NCOL][NTL], double (&inc)[NCOL][NTL])
+{
+#pragma unroll
+    for (int q = 0; q < NCOL; ++q)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) inc[q][t] = A[q] * (kn[q][t] - ko[q][t]);
+}
+
+// One move loop of a sweep: n_it proposals of NCOL simultaneous delta shifts.
+// Returns the number of accepted proposals.
+template <int NCOL, int MOVE, int DEPTH, int NTL, bool LOG>
+__device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
+{
+    int accepted = 0;
+    for (int base = 0; base < n_it; base += 64) {
+        const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
+        Decoded<NCOL> d;
+        decode<NCOL, NTL>(c, MOVE, (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1)), window, d);
+
+        // prefetch ring: columns of proposals j .. j+DEPTH-1
+        double kn[DEPTH][NCOL][NTL], ko[DEPTH][NCOL][NTL];
+        int is_old[DEPTH][NCOL], is_new[DEPTH][NCOL];
+        auto issue = [&](auto U, int j) {
+            constexpr int u = decltype(U)::value;
+            const int jj = (j < cnt) ? j : cnt - 1;
+            const int inb = __builtin_amdgcn_readlane(d.inb, jj);
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) {
+                const int o = __builtin_amdgcn_readlane(d.wold[q], jj);
+                const int nw = inb ? __builtin_amdgcn_readlane(d.wnew[q], jj) : o;
+                is_old[u][q] = o;
+                is_new[u][q] = nw;
+                load_col<NTL>(c, nw, kn[u][q]);
+                load_col<NTL>(c, o, ko[u][q]);
+            }
+        };
+        auto resolve = [&](auto U, int j) {
+            constexpr int u = decltype(U)::value;
+            const int inb = __builtin_amdgcn_readlane(d.inb, j);
+            int acc = 0;
+            double chi2_new = 0.0;
+            if (inb) {
+                int s_k[NCOL], s_old[NCOL], s_new[NCOL];
+                double s_A[NCOL];
+                bool fresh = true;
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) {
+                    s_k[q] = __builtin_amdgcn_readlane(d.k[q], j);
+                    s_old[q] = __builtin_amdgcn_readlane(d.wold[q], j);
+                    s_new[q] = __builtin_amdgcn_readlane(d.wnew[q], j);
+                    s_A[q] = c.uniform_A ? c.A_uniform : readlane_f64(d.A[q], j);
+                    fresh = fresh && (s_old[q] == is_old[u][q]) && (s_new[q] == is_new[u][q]);
+                }
+                double inc[NCOL][NTL];
+                if (fresh) {
+                    increments<NCOL, NTL>(s_A, kn[u], ko[u], inc);
+                } else {
+                    // a delta of this proposal moved after its columns were requested
+                    double fn[NCOL][NTL], fo[NCOL][NTL];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) {
+                        load_col<NTL>(c, s_new[q], fn[q]);
+                        load_col<NTL>(c, s_old[q], fo[q]);
+                    }
+                    increments<NCOL, NTL>(s_A, fn, fo, inc);
+                }
+                double gnew[NTL], term = 0.0;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    double g = c.gbar[t];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) g = g + inc[q][t];
+                    gnew[t] = g;
+                    const double e = (g - c.G[t]) * c.sinv[t];        // free:259-261
+                    const double e2 = e * e;
+                    term = (t == 0) ? e2 : (term + e2);
+                }
+                chi2_new = wave_sum_uniform(term);
+                const double u_acc = readlane_f64(d.uacc, j);
+                acc = metropolis(c.chi2, chi2_new, c.inv2theta, u_acc) ? 1 : 0;
+                c.n_eval += 1;
+                if (acc) {                                            // free:310-318
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];
+                    c.chi2 = chi2_new;
+                    if (chi2_new < c.chi2_min) c.chi2_min = chi2_new;
+                    if (c.lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < NCOL; ++q) c.wi[s_k[q]] = (uint32_t)s_new[q];
+                    }
+                    accepted += 1;
+                    c.n_acc += 1;
+                    c.n_accmoves += NCOL;
+                    // later proposals of this group that use a moved delta: decode again
+                    bool hit = false;
+#pragma unroll
+                    for (int a = 0; a < NCOL; ++a)
+#pragma unroll
+                        for (int b = 0; b < NCOL; ++b) hit = hit || (d.k[a] == s_k[b]);
+                    hit = hit && (c.lane > j);
+                    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                        if (hit) {
+#pragma unroll
+                            for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];
+                            compute_new<NCOL>(d, c.gmax);
+                        }
+                    }
+                }
+            }
+            c.n_prop += 1;
+            if constexpr (LOG) {
+                if (c.log != nullptr) {
+                    if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {
+                        MoveRec r;
+                        r.chi2_new = inb ? chi2_new : 0.0;
+                        r.flags = (inb ? 1 : 0) | (acc ? 2 : 0);
+                        r.move = MOVE;
+                        c.log[c.log_pos] = r;
+                    }
+                    c.log_pos += 1;
+                }
+            }
+        };
+
+        // prologue
+        [&]<int... Us>(std::integer_sequence<int, Us...>) {
+            (issue(std::integral_constant<int, Us>{}, Us), ...);
+        }(std::make_integer_sequence<int, DEPTH>{});
+
+        for (int j0 = 0; j0 < cnt; j0 += DEPTH) {
+            [&]<int... Us>(std::integer_sequence<int, Us...>) {
+                // the next request is issued unconditionally (clamped into the group) so that
+                // the compiler can count outstanding loads exactly (partial vmcnt waits)
+                (((j0 + Us < cnt) ? (resolve(std::integral_constant<int, Us>{}, j0 + Us), 0) : 0,
+                  issue(std::integral_constant<int, Us>{}, j0 + Us + DEPTH)), ...);
+            }(std::make_integer_sequence<int, DEPTH>{});
+        }
+    }
+    return accepted;
+}
+
+}  // namespace sacdev

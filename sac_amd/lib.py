@@ -1,0 +1,190 @@
+"""ctypes binding of include/sac_hip.h (the same entry points a Julia `ccall` would bind)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsac_hip.so")
+_LIB = None
+
+EXPORTS = [
+    "sac_last_error", "sac_create", "sac_destroy", "sac_upload_problem", "sac_set_state",
+    "sac_get_state", "sac_init_gbar", "sac_get_gbar", "sac_set_gbar", "sac_adjust_windows",
+    "sac_sample", "sac_get_stats", "sac_get_chain_stats", "sac_get_histogram",
+    "sac_get_histogram_sum_device", "sac_set_move_log", "sac_get_move_log",
+]
+
+HIST_REFERENCE, HIST_ACCUMULATE = 0, 1
+
+
+class SacError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("par", C.c_int32), ("symm", C.c_int32), ("n_tau", C.c_int32),
+                ("n_omega", C.c_int32), ("n_chains", C.c_int32), ("n_grid", C.c_int64),
+                ("wi_0", C.c_int64), ("wi_m", C.c_int64), ("seed", C.c_uint64),
+                ("chain_offset", C.c_uint32), ("device", C.c_int32), ("hist_mode", C.c_int32),
+                ("hist_copies", C.c_int32), ("sweeps_per_launch", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("sampled_chi2", C.c_double), ("chi2_min", C.c_double),
+                ("accept_rates", C.c_double * 6), ("windows", C.c_double * 4),
+                ("proposals", C.c_uint64), ("evaluated", C.c_uint64), ("accepted", C.c_uint64),
+                ("accepted_moves", C.c_uint64), ("sweeps", C.c_uint64),
+                ("last_stage_ms", C.c_double), ("last_kernel_ms", C.c_double),
+                ("last_kernel_launches", C.c_int64)]
+
+
+MOVE_REC = np.dtype([("chi2_new", "<f8"), ("flags", "<i4"), ("move", "<i4")])
+
+
+def load_library():
+    """Loads libsac_hip.so; there is no fallback -- a missing library is an error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SacError(f"{LIB_PATH} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
+                       "sac_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    L.sac_last_error.restype = C.c_char_p
+    L.sac_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.sac_destroy.argtypes = [vp]
+    L.sac_upload_problem.argtypes = [vp, dp, dp, dp]
+    L.sac_set_state.argtypes = [vp, C.c_int32, ip, dp, dp]
+    L.sac_get_state.argtypes = [vp, C.c_int32, ip, dp, dp]
+    L.sac_init_gbar.argtypes = [vp]
+    L.sac_get_gbar.argtypes = [vp, C.c_int32, dp, dp, dp]
+    L.sac_set_gbar.argtypes = [vp, C.c_int32, dp, C.c_double, C.c_double]
+    L.sac_adjust_windows.argtypes = [vp, C.c_int64, C.c_double]
+    L.sac_sample.argtypes = [vp, C.c_int64, C.c_double]
+    L.sac_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sac_get_chain_stats.argtypes = [vp, C.c_int32, dp, dp]
+    L.sac_get_histogram.argtypes = [vp, dp]
+    L.sac_get_histogram_sum_device.argtypes = [vp, vp, dp]
+    L.sac_set_move_log.argtypes = [vp, C.c_int32, C.c_int64]
+    L.sac_get_move_log.argtypes = [vp, vp, C.c_int64, ip]
+    for name in EXPORTS:
+        if name != "sac_last_error":
+            getattr(L, name).restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class SacHandle:
+    """One GPU's worth of chains of one problem (thin object wrapper over the C ABI)."""
+
+    def __init__(self, n_tau, n_omega, n_grid, wi_0, wi_m, n_chains=1, par=1, symm=0, seed=0,
+                 chain_offset=0, device=0, hist_mode=HIST_REFERENCE, hist_copies=0,
+                 sweeps_per_launch=0):
+        self.L = load_library()
+        self.cfg = Config(kind=0, par=par, symm=symm, n_tau=n_tau, n_omega=n_omega,
+                          n_chains=n_chains, n_grid=n_grid, wi_0=wi_0, wi_m=wi_m, seed=seed,
+                          chain_offset=chain_offset, device=device, hist_mode=hist_mode,
+                          hist_copies=hist_copies, sweeps_per_launch=sweeps_per_launch)
+        self.h = C.c_void_p()
+        self._check(self.L.sac_create(C.byref(self.cfg), C.byref(self.h)))
+        self.n_tau, self.n_omega, self.n_grid, self.n_chains = n_tau, n_omega, n_grid, n_chains
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SacError(f"libsac_hip error {rc}: {self.L.sac_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.sac_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_problem(self, K, G, sigma_inv):
+        K = np.ascontiguousarray(K, dtype=np.float64)
+        if K.shape != (self.n_grid, self.n_tau):
+            raise SacError(f"K has shape {K.shape}, expected {(self.n_grid, self.n_tau)}")
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        sigma_inv = np.ascontiguousarray(sigma_inv, dtype=np.float64)
+        if G.shape != (self.n_tau,) or sigma_inv.shape != (self.n_tau,):
+            raise SacError("G and sigma_inv must have n_tau entries")
+        self._check(self.L.sac_upload_problem(self.h, _dp(K), _dp(G), _dp(sigma_inv)))
+
+    def set_state(self, wi=None, A=None, windows=None, chain=-1):
+        wi = None if wi is None else np.ascontiguousarray(wi, dtype=np.int64)
+        A = None if A is None else np.ascontiguousarray(A, dtype=np.float64)
+        windows = None if windows is None else np.ascontiguousarray(windows, dtype=np.float64)
+        for a, n in ((wi, self.n_omega), (A, self.n_omega), (windows, 4)):
+            if a is not None and a.shape != (n,):
+                raise SacError(f"state array has shape {a.shape}, expected ({n},)")
+        self._check(self.L.sac_set_state(self.h, chain, _ip(wi), _dp(A), _dp(windows)))
+
+    def get_state(self, chain=0):
+        wi = np.empty(self.n_omega, dtype=np.int64)
+        A = np.empty(self.n_omega)
+        w = np.empty(4)
+        self._check(self.L.sac_get_state(self.h, chain, _ip(wi), _dp(A), _dp(w)))
+        return wi, A, w
+
+    def init_gbar(self):
+        self._check(self.L.sac_init_gbar(self.h))
+
+    def get_gbar(self, chain=0):
+        g = np.empty(self.n_tau)
+        c, m = C.c_double(), C.c_double()
+        self._check(self.L.sac_get_gbar(self.h, chain, _dp(g), C.byref(c), C.byref(m)))
+        return g, c.value, m.value
+
+    def set_gbar(self, gbar, chi2, chi2_min, chain=-1):
+        gbar = np.ascontiguousarray(gbar, dtype=np.float64)
+        self._check(self.L.sac_set_gbar(self.h, chain, _dp(gbar), chi2, chi2_min))
+
+    def adjust_windows(self, steps, theta):
+        self._check(self.L.sac_adjust_windows(self.h, int(steps), float(theta)))
+
+    def sample(self, steps, theta):
+        self._check(self.L.sac_sample(self.h, int(steps), float(theta)))
+
+    def stats(self):
+        s = Stats()
+        self._check(self.L.sac_get_stats(self.h, C.byref(s)))
+        return s
+
+    def chain_stats(self, chain=0):
+        o = np.empty(6)
+        ar = np.empty(6)
+        self._check(self.L.sac_get_chain_stats(self.h, chain, _dp(o), _dp(ar)))
+        return dict(sampled_chi2=o[0], chi2=o[1], chi2_min=o[2], sweeps=int(o[3]), accept_rates=ar)
+
+    def histogram(self):
+        out = np.empty(self.n_grid)
+        self._check(self.L.sac_get_histogram(self.h, _dp(out)))
+        return out
+
+    def histogram_sum_to_device(self, device_ptr):
+        d = C.c_double()
+        self._check(self.L.sac_get_histogram_sum_device(self.h, C.c_void_p(device_ptr), C.byref(d)))
+        return d.value
+
+    def set_move_log(self, chain, capacity):
+        self._check(self.L.sac_set_move_log(self.h, chain, capacity))
+
+    def move_log(self, capacity):
+        out = np.zeros(capacity, dtype=MOVE_REC)
+        n = C.c_int64()
+        self._check(self.L.sac_get_move_log(self.h, out.ctypes.data, capacity, C.byref(n)))
+        return out[:min(n.value, capacity)], n.value
