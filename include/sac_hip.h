@@ -76,6 +76,7 @@ typedef struct {
     uint64_t accepted;         /* accepted proposals */
     uint64_t accepted_moves;   /* accepted proposals weighted by deltas moved (1/2/3) */
     uint64_t sweeps;           /* chain-sweeps since creation */
+    uint64_t columns_gathered; /* K columns read by evaluated proposals (2/4/6 per single/pair/triple) */
     double   last_stage_ms;    /* device time of the last adjust_windows / sample call */
     double   last_kernel_ms;   /* device time spent in the sweep kernel proper during it */
     int64_t  last_kernel_launches;

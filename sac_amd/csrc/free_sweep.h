@@ -26,7 +26,8 @@ struct ChainScalars {
     double acc[6];              // accept_rates accumulators (free:56)
     double sum_chi2;            // sampled_chi2 accumulator (free:919)
     unsigned long long sweep;   // sweeps since creation (Philox counter word)
-    unsigned long long counters[4];   // proposals, evaluated, accepted, accepted delta-moves
+    unsigned long long counters[5];   // proposals, evaluated, accepted, accepted delta-moves,
+                                      // K columns gathered by evaluated proposals
 };
 
 struct MoveRec { double chi2_new; int flags; int move; };
@@ -72,7 +73,7 @@ struct Chain {
     double gbar[NTL], G[NTL], sinv[NTL];
     double chi2, chi2_min, inv2theta;
     uint32_t key0, key1, chain_id, sweep_lo, sweep_hi;
-    unsigned long long n_prop, n_eval, n_acc, n_accmoves;
+    unsigned long long n_prop, n_eval, n_acc, n_accmoves, n_cols;
     // amplitudes
     const double *A;            // this chain's amplitude array (global)
     double A_uniform;
@@ -263,6 +264,7 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
                 const double u_acc = readlane_f64(d.uacc, j);
                 acc = metropolis(c.chi2, chi2_new, c.inv2theta, u_acc) ? 1 : 0;
                 c.n_eval += 1;
+                c.n_cols += 2 * NCOL;
                 if (acc) {                                            // free:310-318
 #pragma unroll
                     for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];

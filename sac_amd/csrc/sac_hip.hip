@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
     c.A = p.A + (size_t)chain * (size_t)p.wi_stride;
     c.A_uniform = p.A_uniform;
     c.uniform_A = p.uniform_A;
-    c.n_prop = c.n_eval = c.n_acc = c.n_accmoves = 0;
+    c.n_prop = c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
     double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
         scp->counters[1] += c.n_eval;
         scp->counters[2] += c.n_acc;
         scp->counters[3] += c.n_accmoves;
+        scp->counters[4] += c.n_cols;
         if constexpr (LOG) {
             if (c.log != nullptr) *p.log_len = c.log_pos;
         }
@@ -660,6 +661,7 @@ extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
         out->evaluated += s.counters[1];
         out->accepted += s.counters[2];
         out->accepted_moves += s.counters[3];
+        out->columns_gathered += s.counters[4];
         out->sweeps += s.sweep;
     }
     out->sampled_chi2 = s_chi2 / (double)nc;

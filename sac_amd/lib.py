@@ -35,6 +35,7 @@ class Stats(C.Structure):
                 ("accept_rates", C.c_double * 6), ("windows", C.c_double * 4),
                 ("proposals", C.c_uint64), ("evaluated", C.c_uint64), ("accepted", C.c_uint64),
                 ("accepted_moves", C.c_uint64), ("sweeps", C.c_uint64),
+                ("columns_gathered", C.c_uint64),
                 ("last_stage_ms", C.c_double), ("last_kernel_ms", C.c_double),
                 ("last_kernel_launches", C.c_int64)]
 
