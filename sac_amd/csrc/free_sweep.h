@@ -66,18 +66,18 @@ constexpr int MAX_N_OMEGA = 2048;
 // Per-wave state that lives in registers for the whole launch.
 template <int NTL>
 struct Chain {
-    const double *K;
+    const char *Kb;             // K table, byte addressed
+    uint32_t col_bytes;         // bytes per (padded) column
     uint32_t *wi;               // LDS
-    int lane, ntp, n_omega, gmax;
-    int idx[NTL];               // this lane's tau slot(s), clamped into the padded column
+    int lane, n_omega, gmax;
+    uint32_t off[NTL];          // byte offset of this lane's tau slot(s), clamped into the column
     double gbar[NTL], G[NTL], sinv[NTL];
     double chi2, chi2_min, inv2theta;
     uint32_t key0, key1, chain_id, sweep_lo, sweep_hi;
-    unsigned long long n_prop, n_eval, n_acc, n_accmoves, n_cols;
+    uint32_t n_eval, n_acc, n_accmoves, n_cols;   // per launch (fits: <= 2^31 proposals per launch)
     // amplitudes
-    const double *A;            // this chain's amplitude array (global)
+    const double *A;            // this chain's amplitude array (global), used when !UA
     double A_uniform;
-    int uniform_A;
     // move log
     MoveRec *log;
     long long log_cap;
@@ -87,24 +87,25 @@ struct Chain {
 template <int NTL>
 __device__ __forceinline__ void load_col(const Chain<NTL> &c, int col, double (&out)[NTL])
 {
-    const double *base = c.K + (size_t)(unsigned)col * (size_t)c.ntp;
+    // wave-uniform 64-bit base (scalar registers) + 32-bit lane offset
+    const char *base = c.Kb + (uint64_t)(uint32_t)col * (uint64_t)c.col_bytes;
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) out[t] = base[c.idx[t]];
+    for (int t = 0; t < NTL; ++t) out[t] = *reinterpret_cast<const double *>(base + c.off[t]);
 }
 
 // One decoded proposal per lane.  NCOL deltas move: k = index, wold/wnew = relative positions.
-template <int NCOL>
+template <int NCOL, bool UA>
 struct Decoded {
     int k[NCOL], wold[NCOL], wnew[NCOL];
     int sd;         // signed shift (single, pair)
     int inb;        // proposal reaches the chi^2 evaluation
     int dead;       // retry blocks exhausted: never evaluated
     double uacc;
-    double A[NCOL];
+    double A[UA ? 1 : NCOL];    // per-delta amplitudes (unused when all amplitudes are equal)
 };
 
-template <int NCOL>
-__device__ __forceinline__ void compute_new(Decoded<NCOL> &d, int gmax)
+template <int NCOL, bool UA>
+__device__ __forceinline__ void compute_new(Decoded<NCOL, UA> &d, int gmax)
 {
     if constexpr (NCOL == 1) {
         d.wnew[0] = d.wold[0] + d.sd;                               // free:287-291
@@ -131,9 +132,9 @@ __device__ __forceinline__ int shift_from_draw(double u_mag, double u_sign, doub
     return (u_sign < 0.5) ? mag : -mag;
 }
 
-template <int NCOL, int NTL>
+template <int NCOL, int NTL, bool UA>
 __device__ __forceinline__ void decode(const Chain<NTL> &c, int move, uint32_t iter, double window,
-                                       Decoded<NCOL> &d)
+                                       Decoded<NCOL, UA> &d)
 {
     const uint32_t c2 = c.sweep_hi | ((uint32_t)move << 16);
     const u32x4 b0 = philox4x32_10(iter, c.sweep_lo, c2, c.chain_id, c.key0, c.key1);
@@ -175,9 +176,9 @@ __device__ __forceinline__ void decode(const Chain<NTL> &c, int move, uint32_t i
 #pragma unroll
     for (int q = 0; q < NCOL; ++q) {
         d.wold[q] = (int)c.wi[d.k[q]];
-        d.A[q] = c.uniform_A ? c.A_uniform : c.A[d.k[q]];
+        if constexpr (!UA) d.A[q] = c.A[d.k[q]];
     }
-    compute_new<NCOL>(d, c.gmax);
+    compute_new<NCOL, UA>(d, c.gmax);
 }
 
 // A_c * (K[:, new] - K[:, old]) for every moved delta (free:301-302, 367-369, 448-451)
@@ -193,14 +194,14 @@ __device__ __forceinline__ void increments(const double (&A)[NCOL], const double
 
 // One move loop of a sweep: n_it proposals of NCOL simultaneous delta shifts.
 // Returns the number of accepted proposals.
-template <int NCOL, int MOVE, int DEPTH, int NTL, bool LOG>
+template <int NCOL, int MOVE, int DEPTH, int NTL, bool LOG, bool UA>
 __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
 {
     int accepted = 0;
     for (int base = 0; base < n_it; base += 64) {
         const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
-        Decoded<NCOL> d;
-        decode<NCOL, NTL>(c, MOVE, (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1)), window, d);
+        Decoded<NCOL, UA> d;
+        decode<NCOL, NTL, UA>(c, MOVE, (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1)), window, d);
 
         // prefetch ring: columns of proposals j .. j+DEPTH-1
         double kn[DEPTH][NCOL][NTL], ko[DEPTH][NCOL][NTL];
@@ -233,7 +234,8 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
                     s_k[q] = __builtin_amdgcn_readlane(d.k[q], j);
                     s_old[q] = __builtin_amdgcn_readlane(d.wold[q], j);
                     s_new[q] = __builtin_amdgcn_readlane(d.wnew[q], j);
-                    s_A[q] = c.uniform_A ? c.A_uniform : readlane_f64(d.A[q], j);
+                    if constexpr (UA) s_A[q] = c.A_uniform;
+                    else s_A[q] = readlane_f64(d.A[q], j);
                     fresh = fresh && (s_old[q] == is_old[u][q]) && (s_new[q] == is_new[u][q]);
                 }
                 double inc[NCOL][NTL];
@@ -288,12 +290,11 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
                         if (hit) {
 #pragma unroll
                             for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];
-                            compute_new<NCOL>(d, c.gmax);
+                            compute_new<NCOL, UA>(d, c.gmax);
                         }
                     }
                 }
             }
-            c.n_prop += 1;
             if constexpr (LOG) {
                 if (c.log != nullptr) {
                     if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {

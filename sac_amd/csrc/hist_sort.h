@@ -91,7 +91,7 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyT (&key)[EPL], int lane)
 //   exclusive  the replica belongs to this chain alone: plain read-modify-write (bit exact);
 //              otherwise fp64 hardware atomics.
 template <typename KeyT, int EPL>
-__device__ __forceinline__ void hist_reference(const uint32_t *wi, int n, const double *A,
+__device__ __attribute__((noinline)) void hist_reference(const uint32_t *wi, int n, const double *A,
                                                double A_uniform, int uniform_A, double *hist,
                                                int exclusive, int lane)
 {

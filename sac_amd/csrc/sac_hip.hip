@@ -23,20 +23,21 @@ using namespace sacdev;
 
 // One launch = n_sweeps sweeps (run_updates, free:825-861) of every chain, plus, by flag, the
 // per-sweep sampling work (free:918-919) and the end-of-round window retune (free:883-895).
-template <int NTL, bool LOG>
+template <int NTL, bool LOG, bool UA>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(const FreeParams p)
 {
     __shared__ uint32_t s_wi[WAVES_PER_BLOCK][MAX_N_OMEGA];
+    __shared__ double s_sc[WAVES_PER_BLOCK][12];   // windows[4], accept accumulators[6], sum chi2
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int chain = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (chain >= p.n_chains) return;
     const int lane = lane_id();
 
     Chain<NTL> c;
-    c.K = p.K;
+    c.Kb = reinterpret_cast<const char *>(p.K);
+    c.col_bytes = (uint32_t)p.ntp * 8u;
     c.wi = s_wi[wave];
     c.lane = lane;
-    c.ntp = p.ntp;
     c.n_omega = p.n_omega;
     c.gmax = p.gmax;
     c.inv2theta = p.inv2theta;
@@ -45,13 +46,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
     c.chain_id = p.chain_offset + (uint32_t)chain;
     c.A = p.A + (size_t)chain * (size_t)p.wi_stride;
     c.A_uniform = p.A_uniform;
-    c.uniform_A = p.uniform_A;
-    c.n_prop = c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
+    c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
     double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const int j = lane + 64 * t;
-        c.idx[t] = (j < p.ntp) ? j : p.ntp - 1;
+        c.off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
         c.gbar[t] = gbar_g[j];
         c.G[t] = p.G[j];
         c.sinv[t] = p.sinv[j];
@@ -62,18 +62,13 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
     ChainScalars *scp = p.sc + chain;
     c.chi2 = scp->chi2;
     c.chi2_min = scp->chi2_min;
-    double win[4], acc[6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) win[k] = scp->windows[k];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] = scp->acc[k];
-    double sum_chi2 = scp->sum_chi2;
+    // rarely touched per-chain scalars stay in LDS, not in registers
+    double *win = s_sc[wave], *acc = s_sc[wave] + 4, *sum_chi2 = s_sc[wave] + 10;
+    const bool zero = (p.flags & STAGE_ZERO_ACC) != 0;
+    if (lane < 4) win[lane] = scp->windows[lane];
+    if (lane < 6) acc[lane] = zero ? 0.0 : scp->acc[lane];
+    if (lane == 0) *sum_chi2 = zero ? 0.0 : scp->sum_chi2;
     unsigned long long sweep = scp->sweep;
-    if (p.flags & STAGE_ZERO_ACC) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] = 0.0;
-        sum_chi2 = 0.0;
-    }
     c.log = nullptr;
     c.log_cap = 0;
     c.log_pos = 0;
@@ -91,32 +86,38 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
         c.sweep_lo = (uint32_t)sweep;
         c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
         int a;
-        a = move_loop<1, 1, 8, NTL, LOG>(c, n, win[0]);             // free:829-830
-        acc[0] += (double)a / (double)n;
-        a = move_loop<2, 2, 4, NTL, LOG>(c, n / 2, win[1]);         // free:832-833
-        acc[1] += (double)(2 * a) / (double)(n / 2);
-        a = move_loop<3, 3, 4, NTL, LOG>(c, n / 3, 0.0);            // free:835-836
-        acc[2] += (double)a / (double)(n / 3);
+        // prefetch depth per move type: two tau slots per lane double the ring's registers
+        constexpr int D1 = (NTL == 1) ? 8 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
+        a = move_loop<1, 1, D1, NTL, LOG, UA>(c, n, win[0]);        // free:829-830
+        if (lane == 0) acc[0] += (double)a / (double)n;
+#ifndef EXP_NO2
+        a = move_loop<2, 2, D2, NTL, LOG, UA>(c, n / 2, win[1]);    // free:832-833
+        if (lane == 0) acc[1] += (double)(2 * a) / (double)(n / 2);
+#endif
+#ifndef EXP_NO3
+        a = move_loop<3, 3, D3, NTL, LOG, UA>(c, n / 3, 0.0);       // free:835-836
+        if (lane == 0) acc[2] += (double)a / (double)(n / 3);
+#endif
+#ifndef EXP_NOHIST
         if (p.flags & STAGE_SAMPLE) {
             if (p.hist_mode == SAC_HIST_REFERENCE) {
                 if (p.n_grid <= (1ll << 21))
-                    hist_reference<uint32_t, 32>(c.wi, n, c.A, c.A_uniform, c.uniform_A, hist,
+                    hist_reference<uint32_t, 32>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
                                                  p.hist_exclusive, lane);
                 else
-                    hist_reference<uint64_t, 32>(c.wi, n, c.A, c.A_uniform, c.uniform_A, hist,
+                    hist_reference<uint64_t, 32>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
                                                  p.hist_exclusive, lane);
             } else {
-                hist_accumulate(c.wi, n, c.A, c.A_uniform, c.uniform_A, hist, lane);
+                hist_accumulate(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist, lane);
             }
-            sum_chi2 += c.chi2;                                      // free:919
+            if (lane == 0) *sum_chi2 += c.chi2;                      // free:919
         }
+#endif
         sweep += 1;
     }
 
-    if (p.flags & STAGE_RETUNE) {                                    // free:883-895
-#pragma unroll
+    if ((p.flags & STAGE_RETUNE) && lane == 0) {                     // free:883-895
         for (int k = 0; k < 6; ++k) acc[k] = acc[k] / p.retune_div;
-#pragma unroll
         for (int k = 0; k < 4; ++k) {
             const double r = acc[k];
             if (r > 0.8) win[k] *= 2;
@@ -137,9 +138,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
         scp->chi2_min = c.chi2_min;
         for (int k = 0; k < 4; ++k) scp->windows[k] = win[k];
         for (int k = 0; k < 6; ++k) scp->acc[k] = acc[k];
-        scp->sum_chi2 = sum_chi2;
+        scp->sum_chi2 = *sum_chi2;
         scp->sweep = sweep;
-        scp->counters[0] += c.n_prop;
+        scp->counters[0] += (unsigned long long)p.n_sweeps * (unsigned long long)(n + n / 2 + n / 3);
         scp->counters[1] += c.n_eval;
         scp->counters[2] += c.n_acc;
         scp->counters[3] += c.n_accmoves;
@@ -562,12 +563,17 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
         }
         HIP_TRY(hipEventRecord(h->kev[li].first, h->stream));
         const dim3 grid(grid_blocks(h)), block(64 * WAVES_PER_BLOCK);
-        if (h->cfg.n_tau <= 64) {
-            if (log) hipLaunchKernelGGL((free_stage_kernel<1, true>), grid, block, 0, h->stream, p);
-            else hipLaunchKernelGGL((free_stage_kernel<1, false>), grid, block, 0, h->stream, p);
-        } else {
-            if (log) hipLaunchKernelGGL((free_stage_kernel<2, true>), grid, block, 0, h->stream, p);
-            else hipLaunchKernelGGL((free_stage_kernel<2, false>), grid, block, 0, h->stream, p);
+        const bool ua = h->uniform_A;
+        const int variant = (h->cfg.n_tau <= 64 ? 0 : 4) | (log ? 2 : 0) | (ua ? 1 : 0);
+        switch (variant) {
+        case 0: hipLaunchKernelGGL((free_stage_kernel<1, false, false>), grid, block, 0, h->stream, p); break;
+        case 1: hipLaunchKernelGGL((free_stage_kernel<1, false, true>), grid, block, 0, h->stream, p); break;
+        case 2: hipLaunchKernelGGL((free_stage_kernel<1, true, false>), grid, block, 0, h->stream, p); break;
+        case 3: hipLaunchKernelGGL((free_stage_kernel<1, true, true>), grid, block, 0, h->stream, p); break;
+        case 4: hipLaunchKernelGGL((free_stage_kernel<2, false, false>), grid, block, 0, h->stream, p); break;
+        case 5: hipLaunchKernelGGL((free_stage_kernel<2, false, true>), grid, block, 0, h->stream, p); break;
+        case 6: hipLaunchKernelGGL((free_stage_kernel<2, true, false>), grid, block, 0, h->stream, p); break;
+        default: hipLaunchKernelGGL((free_stage_kernel<2, true, true>), grid, block, 0, h->stream, p); break;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
