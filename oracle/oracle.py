@@ -33,8 +33,8 @@ def lib():
     ip = C.POINTER(C.c_int64)
     vp = C.c_void_p
     L.ora_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
-    L.ora_exp_neg.restype = C.c_double
-    L.ora_exp_neg.argtypes = [C.c_double]
+    L.ora_log_u01.restype = C.c_double
+    L.ora_log_u01.argtypes = [C.c_double]
     L.ora_chi2.restype = C.c_double
     L.ora_chi2.argtypes = [dp, dp, dp, C.c_int]
     L.ora_free_create.restype = vp
@@ -87,8 +87,8 @@ def philox(ctr, key):
     return [int(x) for x in o]
 
 
-def exp_neg(x):
-    return lib().ora_exp_neg(float(x))
+def log_u01(u):
+    return lib().ora_log_u01(float(u))
 
 
 def chi2(gbar, g, sinv):

@@ -131,33 +131,35 @@ static int64_t draw_R_retry(prop_t *p, uint32_t *retry, int sel, int64_t n)
 /* Arithmetic shared by spec with the HIP kernels                           */
 /* ------------------------------------------------------------------------ */
 
-/* exp(x), x < 0.  k = rint(x log2 e); r = x - k ln2 (two-step fma);
- * degree-13 Taylor polynomial by Horner with fma; scale by 2^k.
- * Returns 0 for x <= -708 or NaN.  Max error < 1 ulp (tests/test_oracle_rng.py). */
-double ora_exp_neg(double x)
+/* ln(u) for a draw u in [0,1); ln(0) = -inf.  Reduction u = 2^k (1+f) with
+ * sqrt(1/2) < 1+f < sqrt(2), s = f/(2+f), even polynomial in s (the classical
+ * fdlibm scheme, general branch only); basic IEEE operations in a fixed order, so
+ * the HIP kernels' own implementation of the same sequence agrees bit for bit.
+ * Max error < 1 ulp (tests/test_oracle_rng.py). */
+double ora_log_u01(double u)
 {
-    if (!(x > -708.0)) return 0.0;
-    const double LOG2E  = 1.4426950408889634074;
-    const double LN2_HI = 6.93147180369123816490e-01;
-    const double LN2_LO = 1.90821492927058770002e-10;
-    double k = rint(x * LOG2E);
-    double r = fma(-k, LN2_HI, x);
-    r = fma(-k, LN2_LO, r);
-    double p = 1.6059043836821614599e-10;            /* 1/13! */
-    p = fma(p, r, 2.0876756987868098979e-09);        /* 1/12! */
-    p = fma(p, r, 2.5052108385441718775e-08);        /* 1/11! */
-    p = fma(p, r, 2.7557319223985890653e-07);        /* 1/10! */
-    p = fma(p, r, 2.7557319223985892511e-06);        /* 1/9!  */
-    p = fma(p, r, 2.4801587301587301566e-05);        /* 1/8!  */
-    p = fma(p, r, 1.9841269841269841253e-04);        /* 1/7!  */
-    p = fma(p, r, 1.3888888888888889419e-03);        /* 1/6!  */
-    p = fma(p, r, 8.3333333333333332177e-03);        /* 1/5!  */
-    p = fma(p, r, 4.1666666666666664354e-02);        /* 1/4!  */
-    p = fma(p, r, 1.6666666666666665741e-01);        /* 1/3!  */
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)k);
+    if (!(u > 0.0)) return -INFINITY;
+    uint64_t bits;
+    memcpy(&bits, &u, 8);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    const uint32_t lx = (uint32_t)bits;
+    int k = (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    const uint64_t mb = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | lx;
+    double m;
+    memcpy(&m, &mb, 8);
+    k += (int)(i >> 20);
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
 /* Canonical 64-slot pairwise tree: slot l = t[l] (+ t[l+64]); missing slots are +0.
@@ -242,13 +244,12 @@ static void log_move(ora_free_t *s, int move, int evaluated, int accepted, doubl
     s->log_len++;
 }
 
-/* Metropolis test.  free:307-309: P = exp((chi2 - chi2_new)/(2 theta)); rand() <= P */
+/* Metropolis test.  free:307-309: P = exp((chi2 - chi2_new)/(2 theta)); rand() <= P.
+ * Restated in the log domain: u <= exp(x)  <=>  ln u <= x  (x NaN: false, as in Julia). */
 static int metropolis(double chi2, double chi2_new, double inv2theta, double u)
 {
     double x = (chi2 - chi2_new) * inv2theta;
-    if (x != x) return 0;               /* rand() <= NaN is false */
-    if (x >= 0.0) return 1;             /* P >= 1 > u */
-    return u <= ora_exp_neg(x);
+    return x >= ora_log_u01(u);
 }
 
 /* free:310-318 (and the identical commit blocks of the other moves) */

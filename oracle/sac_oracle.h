@@ -17,9 +17,10 @@
  * Deliberate, documented differences from the Julia text (DESIGN.md "Oracle"):
  *   - chi^2 is summed in ONE defined order (64-slot pairwise tree); Julia's
  *     @simd reduction order is CPU dependent (free:251,259).
- *   - the Metropolis probability uses sac_exp_neg() (own <1ulp exp, fma based)
- *     and x = (chi2-chi2_new) * (1/(2 theta)); Julia uses @fastmath exp
- *     (free:307) of an unpinned Julia version.  P >= 1 short-circuits.
+ *   - the Metropolis test rand() <= exp(x), x = (chi2-chi2_new)/(2 theta), is
+ *     evaluated as x >= ln(rand()) with x = (chi2-chi2_new) * (1/(2 theta)) and an
+ *     own <1ulp ln; Julia uses @fastmath exp (free:307) of an unpinned Julia
+ *     version, so its decisions at the rounding edge are not reproducible anyway.
  *   - random draws come from an injected source: Philox4x32-10 fixed-slot
  *     stream (shared spec with the HIP kernels) or an explicit trace consumed
  *     in the reference's call order.
@@ -47,8 +48,8 @@ typedef struct ora_free ora_free_t;
 
 /* Philox4x32-10 block; exported for known-answer tests. */
 void ora_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
-/* exp(x) for x < 0 as used in the accept test; exported for accuracy tests. */
-double ora_exp_neg(double x);
+/* ln(u) as used in the accept test; exported for accuracy tests. */
+double ora_log_u01(double u);
 /* chi^2 = sum_j ((gbar_j - g_j) * sinv_j)^2 in the canonical tree order. */
 double ora_chi2(const double *gbar, const double *g, const double *sinv, int n_tau);
 

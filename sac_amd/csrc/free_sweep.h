@@ -84,11 +84,16 @@ struct Chain {
     unsigned long long log_pos;
 };
 
+// Column `col` of the K table for this lane's tau slot(s).  The 64-bit column base is formed in
+// scalar registers (s_mul_i32 / s_mul_hi_u32; col is wave-uniform), so each load is one
+// global_load_dwordx2 with an SGPR base and a 32-bit lane offset and costs no vector ALU work.
 template <int NTL>
 __device__ __forceinline__ void load_col(const Chain<NTL> &c, int col, double (&out)[NTL])
 {
-    // wave-uniform 64-bit base (scalar registers) + 32-bit lane offset
-    const char *base = c.Kb + (uint64_t)(uint32_t)col * (uint64_t)c.col_bytes;
+    uint32_t lo, hi;
+    asm("s_mul_i32 %0, %1, %2" : "=s"(lo) : "s"(col), "s"(c.col_bytes));
+    asm("s_mul_hi_u32 %0, %1, %2" : "=s"(hi) : "s"(col), "s"(c.col_bytes));
+    const char *base = c.Kb + (((uint64_t)hi << 32) | lo);
 #pragma unroll
     for (int t = 0; t < NTL; ++t) out[t] = *reinterpret_cast<const double *>(base + c.off[t]);
 }
@@ -100,7 +105,7 @@ struct Decoded {
     int sd;         // signed shift (single, pair)
     int inb;        // proposal reaches the chi^2 evaluation
     int dead;       // retry blocks exhausted: never evaluated
-    double uacc;
+    double lnu;     // ln of the Metropolis draw (free:309), prepared off the sequential path
     double A[UA ? 1 : NCOL];    // per-delta amplitudes (unused when all amplitudes are equal)
 };
 
@@ -166,12 +171,12 @@ __device__ __forceinline__ void decode(const Chain<NTL> &c, int move, uint32_t i
     }
     if constexpr (NCOL == 1) {
         d.sd = shift_from_draw(u01(b0.y, b0.z), u01(b0.w, b1.x), window);
-        d.uacc = u01(b1.y, b1.z);
+        d.lnu = log_u01(u01(b1.y, b1.z));
     } else if constexpr (NCOL == 2) {
         d.sd = shift_from_draw(u01(b0.z, b0.w), u01(b1.x, b1.y), window);
-        d.uacc = u01(b1.z, b1.w);
+        d.lnu = log_u01(u01(b1.z, b1.w));
     } else {
-        d.uacc = u01(b0.w, b1.x);
+        d.lnu = log_u01(u01(b0.w, b1.x));
     }
 #pragma unroll
     for (int q = 0; q < NCOL; ++q) {
@@ -203,13 +208,18 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
         Decoded<NCOL, UA> d;
         decode<NCOL, NTL, UA>(c, MOVE, (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1)), window, d);
 
-        // prefetch ring: columns of proposals j .. j+DEPTH-1
+        // prefetch ring: columns of proposals j .. j+DEPTH-1, and what was requested for each
         double kn[DEPTH][NCOL][NTL], ko[DEPTH][NCOL][NTL];
-        int is_old[DEPTH][NCOL], is_new[DEPTH][NCOL];
+        int is_inb[DEPTH], is_old[DEPTH][NCOL], is_new[DEPTH][NCOL];
+        // lanes (= proposals of this group) re-decoded after their columns were requested
+        unsigned long long stale = 0ull;
+
         auto issue = [&](auto U, int j) {
             constexpr int u = decltype(U)::value;
             const int jj = (j < cnt) ? j : cnt - 1;
             const int inb = __builtin_amdgcn_readlane(d.inb, jj);
+            is_inb[u] = inb;
+            if (j < cnt) stale &= ~(1ull << j);   // fresh values are read here (not for a clamped re-issue)
 #pragma unroll
             for (int q = 0; q < NCOL; ++q) {
                 const int o = __builtin_amdgcn_readlane(d.wold[q], jj);
@@ -222,27 +232,32 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
         };
         auto resolve = [&](auto U, int j) {
             constexpr int u = decltype(U)::value;
-            const int inb = __builtin_amdgcn_readlane(d.inb, j);
+            int inb = is_inb[u];
+            int s_old[NCOL], s_new[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) { s_old[q] = is_old[u][q]; s_new[q] = is_new[u][q]; }
+            const bool was_stale = ((stale >> j) & 1ull) != 0ull;
+            if (was_stale) {                 // rare: a delta of this proposal moved meanwhile
+                inb = __builtin_amdgcn_readlane(d.inb, j);
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) {
+                    s_old[q] = __builtin_amdgcn_readlane(d.wold[q], j);
+                    s_new[q] = __builtin_amdgcn_readlane(d.wnew[q], j);
+                }
+            }
             int acc = 0;
             double chi2_new = 0.0;
             if (inb) {
-                int s_k[NCOL], s_old[NCOL], s_new[NCOL];
                 double s_A[NCOL];
-                bool fresh = true;
 #pragma unroll
                 for (int q = 0; q < NCOL; ++q) {
-                    s_k[q] = __builtin_amdgcn_readlane(d.k[q], j);
-                    s_old[q] = __builtin_amdgcn_readlane(d.wold[q], j);
-                    s_new[q] = __builtin_amdgcn_readlane(d.wnew[q], j);
                     if constexpr (UA) s_A[q] = c.A_uniform;
                     else s_A[q] = readlane_f64(d.A[q], j);
-                    fresh = fresh && (s_old[q] == is_old[u][q]) && (s_new[q] == is_new[u][q]);
                 }
                 double inc[NCOL][NTL];
-                if (fresh) {
+                if (!was_stale) {
                     increments<NCOL, NTL>(s_A, kn[u], ko[u], inc);
                 } else {
-                    // a delta of this proposal moved after its columns were requested
                     double fn[NCOL][NTL], fo[NCOL][NTL];
 #pragma unroll
                     for (int q = 0; q < NCOL; ++q) {
@@ -263,8 +278,8 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
                     term = (t == 0) ? e2 : (term + e2);
                 }
                 chi2_new = wave_sum_uniform(term);
-                const double u_acc = readlane_f64(d.uacc, j);
-                acc = metropolis(c.chi2, chi2_new, c.inv2theta, u_acc) ? 1 : 0;
+                const double ln_u = readlane_f64(d.lnu, j);
+                acc = metropolis(c.chi2, chi2_new, c.inv2theta, ln_u) ? 1 : 0;
                 c.n_eval += 1;
                 c.n_cols += 2 * NCOL;
                 if (acc) {                                            // free:310-318
@@ -272,6 +287,9 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
                     for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];
                     c.chi2 = chi2_new;
                     if (chi2_new < c.chi2_min) c.chi2_min = chi2_new;
+                    int s_k[NCOL];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) s_k[q] = __builtin_amdgcn_readlane(d.k[q], j);
                     if (c.lane == 0) {
 #pragma unroll
                         for (int q = 0; q < NCOL; ++q) c.wi[s_k[q]] = (uint32_t)s_new[q];
@@ -286,7 +304,9 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
 #pragma unroll
                         for (int b = 0; b < NCOL; ++b) hit = hit || (d.k[a] == s_k[b]);
                     hit = hit && (c.lane > j);
-                    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
+                    if (hits != 0ull) {
+                        stale |= hits;
                         if (hit) {
 #pragma unroll
                             for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];

@@ -4,7 +4,7 @@
 // spec"); the oracle has its own independent C implementation of each:
 //   * philox4x32_10        -- counter-based draws
 //   * u01 / index_from_word
-//   * exp_neg              -- exp(x), x < 0, fma Horner, < 1 ulp
+//   * log_u01              -- ln of a draw, fdlibm-style, < 1 ulp
 //   * wave_sum_uniform     -- the canonical 64-slot pairwise tree
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,29 +24,41 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
 }
 
+// v's image under a DPP lane permutation; every lane is written (bound_ctrl), no old value needed
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
 {
     const uint64_t b = __builtin_bit_cast(uint64_t, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// row broadcast (lane 15 of the previous row / lane 31) into the rows of ROW_MASK; other rows get +0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_bcast_f64(double v)
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xF, false);
     return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
 // Sum of one double per lane in the canonical tree order: levels pair lane l with l^1, l^2,
 // l^4 ... l^32 (fp add is commutative, so every lane of a pair holds the same bits).  Levels 1-2
 // are quad permutes, 4 and 8 the half-row / row mirrors (a lane's mirror image lies in the other
-// half, whose lanes all hold the same partial sum), 16 and 32 go through scalar registers.
-// The result is wave-uniform.
+// half, whose lanes all hold the same partial sum); then row sums R0..R3: rows 1 and 3 add their
+// predecessor's (row_bcast15: R1+R0, R3+R2), row 3 adds lane 31's (R3+R2)+(R1+R0), and lane 63 is
+// read into scalar registers.  The result is wave-uniform.
 __device__ __forceinline__ double wave_sum_uniform(double v)
 {
     v = v + dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  : l ^ 1
     v = v + dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : l ^ 2
     v = v + dpp_f64<0x141>(v);   // row_half_mirror      : other quad of the 8-group
     v = v + dpp_f64<0x140>(v);   // row_mirror           : other half of the 16-row
-    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16);
-    const double r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
-    return (r0 + r1) + (r2 + r3);
+    v = v + dpp_bcast_f64<0x142, 0xA>(v);   // row_bcast15 into rows 1, 3
+    v = v + dpp_bcast_f64<0x143, 0xC>(v);   // row_bcast31 into rows 2, 3
+    return readlane_f64(v, 63);
 }
 
 // ---- draws -----------------------------------------------------------------------------
@@ -76,39 +88,40 @@ __device__ __forceinline__ double u01(uint32_t a, uint32_t b)
 // rand(1:n) - 1 from one word
 __device__ __forceinline__ int index_from_word(uint32_t w, uint32_t n) { return (int)__umulhi(w, n); }
 
-// ---- exp -------------------------------------------------------------------------------
+// ---- Metropolis ----------------------------------------------------------------------
 
-// exp(x) for x < 0; 0 for x <= -708 or NaN.  Same operation sequence as the oracle's.
-__device__ __forceinline__ double exp_neg(double x)
+// ln(u) for a draw u in [0,1) (multiples of 2^-53); ln(0) = -inf.  fdlibm-style reduction
+// u = 2^k (1+f), s = f/(2+f), degree-14 even polynomial; basic IEEE operations only, in this
+// fixed order, so the CPU oracle's own implementation of the same sequence agrees bit for bit.
+__device__ __forceinline__ double log_u01(double u)
 {
-    if (!(x > -708.0)) return 0.0;
-    const double k = __builtin_rint(x * 1.4426950408889634074);
-    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
-    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;
-    p = __builtin_fma(p, r, 2.0876756987868098979e-09);
-    p = __builtin_fma(p, r, 2.5052108385441718775e-08);
-    p = __builtin_fma(p, r, 2.7557319223985890653e-07);
-    p = __builtin_fma(p, r, 2.7557319223985892511e-06);
-    p = __builtin_fma(p, r, 2.4801587301587301566e-05);
-    p = __builtin_fma(p, r, 1.9841269841269841253e-04);
-    p = __builtin_fma(p, r, 1.3888888888888889419e-03);
-    p = __builtin_fma(p, r, 8.3333333333333332177e-03);
-    p = __builtin_fma(p, r, 4.1666666666666664354e-02);
-    p = __builtin_fma(p, r, 1.6666666666666665741e-01);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)k);
+    if (!(u > 0.0)) return -__builtin_inf();
+    const uint64_t bits = __builtin_bit_cast(uint64_t, u);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    const uint32_t lx = (uint32_t)bits;
+    int k = (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    const double m = __builtin_bit_cast(double, ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | lx);
+    k += (int)(i >> 20);
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1;
+    const double hfsq = (0.5 * f) * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
-// Metropolis test  rand() <= exp((chi2 - chi2_new)/(2 theta))   (free:307-309)
-__device__ __forceinline__ bool metropolis(double chi2, double chi2_new, double inv2theta, double u)
+// Metropolis test.  The reference draws u = rand() and accepts when u <= exp((chi2-chi2_new)/(2 theta))
+// (free:307-309); here, equivalently, when (chi2 - chi2_new) * (1/(2 theta)) >= ln u, with ln u
+// prepared per proposal off the sequential path.  NaN never accepts.
+__device__ __forceinline__ bool metropolis(double chi2, double chi2_new, double inv2theta, double ln_u)
 {
-    const double x = (chi2 - chi2_new) * inv2theta;
-    if (x != x) return false;
-    if (x >= 0.0) return true;
-    return u <= exp_neg(x);
+    return (chi2 - chi2_new) * inv2theta >= ln_u;
 }
 
 }  // namespace sacdev

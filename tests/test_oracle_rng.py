@@ -15,20 +15,20 @@ def test_philox_known_answers():
                       [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
-def test_exp_neg_accuracy():
+def test_log_u01_accuracy():
     rng = np.random.default_rng(7)
-    xs = np.concatenate([-np.exp(rng.uniform(-30, math.log(707.0), 20000)),
-                         -rng.uniform(0, 40, 20000)])
+    us = np.concatenate([rng.random(30000), np.exp(-rng.uniform(0, 36, 20000)),
+                         1.0 - np.exp(-rng.uniform(0, 36, 5000)), [2.0 ** -53, 1 - 2.0 ** -53, 0.5, 0.25]])
+    us = np.floor(us * 2.0 ** 53) / 2.0 ** 53
+    us = us[(us > 0) & (us < 1)]
     worst = 0.0
-    for x in xs:
-        got = ora.exp_neg(x)
-        ref = math.exp(x)
-        ulp = math.ulp(ref)
-        worst = max(worst, abs(got - ref) / ulp)
+    for u in us:
+        got = ora.log_u01(u)
+        ref = math.log(u)
+        worst = max(worst, abs(got - ref) / math.ulp(ref))
     assert worst <= 1.0, worst
-    assert ora.exp_neg(-708.0) == 0.0 and ora.exp_neg(-1e9) == 0.0
-    assert ora.exp_neg(float("nan")) == 0.0
-    assert ora.exp_neg(-1e-300) == 1.0
+    assert ora.log_u01(0.0) == -math.inf
+    assert ora.log_u01(0.5) == math.log(0.5)
 
 
 def test_chi2_tree_matches_plain_sum():
