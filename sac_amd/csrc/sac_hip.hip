@@ -395,9 +395,11 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
                             (long long)wi[i], (long long)h->cfg.wi_0, (long long)h->cfg.wi_m);
             rel[i] = (uint32_t)(wi[i] - h->cfg.wi_0);
         }
-        for (int c = first; c < first + count; ++c)
-            HIP_TRY(hipMemcpy(h->dWi + (size_t)c * h->wi_stride, rel.data(),
-                              (size_t)h->wi_stride * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::vector<uint32_t> all((size_t)count * (size_t)h->wi_stride);
+        for (int c = 0; c < count; ++c)
+            std::memcpy(all.data() + (size_t)c * h->wi_stride, rel.data(), (size_t)h->wi_stride * sizeof(uint32_t));
+        HIP_TRY(hipMemcpy(h->dWi + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(uint32_t),
+                          hipMemcpyHostToDevice));
         h->state_set = true;
     }
     if (A) {
@@ -408,9 +410,11 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
         }
         std::vector<double> pad((size_t)h->wi_stride, 0.0);
         std::memcpy(pad.data(), A, (size_t)n * sizeof(double));
-        for (int c = first; c < first + count; ++c)
-            HIP_TRY(hipMemcpy(h->dA + (size_t)c * h->wi_stride, pad.data(),
-                              (size_t)h->wi_stride * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<double> all((size_t)count * (size_t)h->wi_stride);
+        for (int c = 0; c < count; ++c)
+            std::memcpy(all.data() + (size_t)c * h->wi_stride, pad.data(), (size_t)h->wi_stride * sizeof(double));
+        HIP_TRY(hipMemcpy(h->dA + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(double),
+                          hipMemcpyHostToDevice));
         if (chain == -1 || h->cfg.n_chains == 1) {
             h->uniform_A = uni;
             h->A_uniform = A[0];

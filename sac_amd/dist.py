@@ -1,0 +1,66 @@
+"""Multi-GPU merge for the sampling stages: one process per GPU (torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The path shards: independent chains are block-partitioned over ranks (the Philox key carries the
+global chain id, so a chain's trajectory does not depend on the rank count) and no collective
+runs inside a stage.  After a stage every rank holds partial sums; ONE fused all-reduce(sum) of
+[histogram | chi2 sum | accept rates | windows | chain count] plus one all-reduce(min) for
+chi2_min merge them, so every rank evaluates the same Theta-schedule predicates
+(free:1087, 1128, 1249-1252).  The reference has no counterpart: its only fan-out is one Julia
+process per parameter point / replica with files as the hand-off.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.distributed as dist
+
+
+def shard_chains(n_total, rank, world):
+    """Block partition: (first global chain id, number of chains) of `rank`."""
+    base, rem = divmod(n_total, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+class Comm:
+    """Stage-level merge over a process group."""
+
+    def __init__(self, group=None, device="cpu"):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+
+    def merge_scalars(self, n_chains, sampled_chi2, chi2_min, accept_rates, windows):
+        """Chain-weighted means (min for chi2_min) over all ranks."""
+        buf = torch.tensor([sampled_chi2 * n_chains, *[a * n_chains for a in accept_rates],
+                            *[w * n_chains for w in windows], float(n_chains)],
+                           dtype=torch.float64, device=self.device)
+        mn = torch.tensor([chi2_min], dtype=torch.float64, device=self.device)
+        dist.all_reduce(buf, group=self.group)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+        buf = buf.cpu()
+        n = float(buf[-1])
+        return SimpleNamespace(sampled_chi2=float(buf[0]) / n, chi2_min=float(mn.cpu()[0]),
+                               accept_rates=[float(x) / n for x in buf[1:7]],
+                               windows=[float(x) / n for x in buf[7:11]], n_chains=int(n))
+
+    def merge_stats(self, st, n_chains=None):
+        """st: sac_stats_t-like (sampled_chi2, chi2_min, accept_rates[6], windows[4])."""
+        n = n_chains if n_chains is not None else getattr(st, "n_chains", 1)
+        return self.merge_scalars(n, st.sampled_chi2, st.chi2_min, list(st.accept_rates)[:6],
+                                  list(st.windows)[:4])
+
+    def merge_histogram_sum(self, hist_sum, divisor):
+        """hist_sum: this rank's un-normalised histogram (tensor on self.device); divisor: its
+        steps*chains.  Returns the merged, normalised histogram (tensor)."""
+        d = torch.tensor([divisor], dtype=torch.float64, device=self.device)
+        dist.all_reduce(hist_sum, group=self.group)
+        dist.all_reduce(d, group=self.group)
+        return hist_sum / d
+
+    def merge_histogram(self, handle):
+        """Histogram of a SacHandle merged over ranks (device-side sum, RCCL all-reduce)."""
+        buf = torch.empty(handle.n_grid, dtype=torch.float64, device=self.device)
+        divisor = handle.histogram_sum_to_device(buf.data_ptr())
+        return self.merge_histogram_sum(buf, divisor).cpu().numpy()

@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size-2 gloo.  Chains are sharded over ranks, each rank runs its chains
+(here through the CPU oracle -- the merge logic under test is backend independent), and the
+per-stage merge (sac_amd/dist.py) must give every rank the statistics and histogram of the
+single-process run over all chains."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import helpers
+
+N_CHAINS, STEPS, THETA, SEED = 5, 6, 2.0, 77
+
+
+def _run_chains(prob, first, count):
+    specs, chi2s, mins, ars, wins = [], [], [], [], []
+    for c in range(first, first + count):
+        o = helpers.oracle_chain(prob, SEED, c)
+        o.adjust_windows(10, THETA)
+        o.sample(STEPS, THETA)
+        specs.append(o.spec() * STEPS)
+        chi2s.append(o.sampled_chi2())
+        mins.append(o.get_gbar()[2])
+        ars.append(o.accept_rates())
+        wins.append(o.get_state()[2])
+    return specs, chi2s, mins, ars, wins
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sac_amd.dist import Comm, shard_chains
+    prob = helpers.problem_golden_bosonic(n_omega=40, omega_m=3.0, d_omega=2e-3)
+    first, count = shard_chains(N_CHAINS, rank, world)
+    specs, chi2s, mins, ars, wins = _run_chains(prob, first, count)
+    comm = Comm()
+    merged = comm.merge_scalars(count, float(np.mean(chi2s)), float(np.min(mins)),
+                                list(np.mean(ars, axis=0)), list(np.mean(wins, axis=0)))
+    hist = comm.merge_histogram_sum(torch.from_numpy(np.sum(specs, axis=0)), float(STEPS * count))
+    out[rank] = dict(first=first, count=count, chi2=merged.sampled_chi2, cmin=merged.chi2_min,
+                     ar=merged.accept_rates, win=merged.windows, n=merged.n_chains,
+                     hist=hist.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_equals_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert (r0["first"], r0["count"], r1["first"], r1["count"]) == (0, 3, 3, 2)
+    prob = helpers.problem_golden_bosonic(n_omega=40, omega_m=3.0, d_omega=2e-3)
+    specs, chi2s, mins, ars, wins = _run_chains(prob, 0, N_CHAINS)
+    for r in (r0, r1):                       # every rank holds the same merged result
+        assert r["n"] == N_CHAINS
+        assert r["cmin"] == min(mins)
+        np.testing.assert_allclose(r["chi2"], np.mean(chi2s), rtol=1e-14)
+        np.testing.assert_allclose(r["ar"], np.mean(ars, axis=0), rtol=1e-13)
+        np.testing.assert_allclose(r["win"], np.mean(wins, axis=0), rtol=1e-13)
+        np.testing.assert_allclose(r["hist"], np.sum(specs, axis=0) / (STEPS * N_CHAINS), rtol=1e-13, atol=0)
+    assert np.array_equal(r0["hist"], r1["hist"]) and r0["chi2"] == r1["chi2"]
+
+
+def test_shard_chains_partitions():
+    from sac_amd.dist import shard_chains
+    for n, w in ((4096, 8), (10, 3), (5, 8), (7, 1)):
+        spans = [shard_chains(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+            assert f0 + c0 == f1

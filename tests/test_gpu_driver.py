@@ -1,0 +1,45 @@
+"""End-to-end driver on the GPU against a committed run of the reference (statistical oracle).
+
+tests/golden/cv/run001a_free_* is sac/cross_validation/out_files/bosonic_delta_peak/001a/free of
+the reference: its in_free.in, and the anneal.csv that real Julia run produced from t_001a.in.
+The RNG of that run is unknown (unseeded), so agreement is statistical: <chi^2>(Theta)/N_tau of
+many GPU chains must follow the reference curve."""
+import os
+
+import numpy as np
+import pytest
+
+from sac_amd.free import FreeSAC
+
+pytestmark = pytest.mark.gpu
+CV = os.path.join(os.path.dirname(__file__), "golden", "cv")
+
+
+def test_anneal_curve_follows_reference_run(tmp_path):
+    s = FreeSAC.from_infile(f"{CV}/run001a_free_in_free.in", n_chains=64, seed=2025)
+    s.G_file = f"{CV}/t_001a.in"
+    s.output_folder = str(tmp_path / "out")
+    s.N_anneal, s.anneal_steps, s.sample_steps = 70, 100, 200     # reference: 150 x 500, 5000
+    s.chi2_anneal = np.zeros(s.N_anneal)
+    s.tol = 1e-6                                                   # cross_val.jl:50
+    theta_opt = s.run()
+    ref = np.loadtxt(f"{CV}/run001a_free_anneal.csv", delimiter=",", skiprows=1)
+    got = np.loadtxt(s.anneal_file, delimiter=",", skiprows=1)
+    n = len(got)
+    assert n == 70
+    assert np.array_equal(got[:, 1], ref[:n, 1])                   # same Theta ladder, same rounding
+    # <chi^2>/N_tau: a single reference chain with 500 sweeps per point scatters by a few percent;
+    # the GPU value is a 64-chain mean
+    ratio = got[:, 3] / ref[:n, 3]
+    assert np.abs(np.log(ratio)).max() < 0.12, ratio
+    assert abs(np.log(ratio).mean()) < 0.03
+    # chi2_min of 64 chains is a minimum over more samples: never far above the single chain's
+    assert (got[10:, 2] < ref[10:n, 2] * 1.05).all()
+    # outputs exist in the reference's layout
+    sw = open(os.path.join(s.output_folder, "sw000.csv")).read().split("\n")
+    assert sw[0] == "omega,S" and len(sw) > 20
+    smp = open(s.sample_file).read().split("\n")
+    assert smp[0] == "i,a,theta,chi2_min,chi2_avg" and len(smp) >= 2
+    log = open(os.path.join(s.output_folder, "log.txt")).read()
+    assert "Beginning Main Anneal." in log and "Final Anneal Finished." in log
+    assert 0 < theta_opt <= 10.0
