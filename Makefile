@@ -19,3 +19,7 @@ clean:
 	rm -f sac_amd/libsac_hip.so; rm -rf build; $(MAKE) -C oracle clean
 
 .PHONY: all oracle clean asm
+
+probe: tools/gather_probe
+tools/gather_probe: tools/gather_probe.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<

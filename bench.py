@@ -135,6 +135,14 @@ def main():
         alg_bytes = cols_r0 * N_TAU * 8 + sweeps_r0 * N_OMEGA * 16   # K columns + histogram RMW
         per_launch_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = alg_bytes / max(launches, 1) / per_launch_s / 1e9
+        traffic = None
+        try:    # PMC-derived traffic of the same launch shape, collected in separate rocprofv3 passes
+            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            w = t["workload"]
+            if (w["n_tau"], w["n_omega"], w["n_grid"], w["chains"]) == (N_TAU, N_OMEGA, prob.n_grid, args.chains):
+                traffic = (2.0 * t["fetch_size_kb_median"] + t["write_size_kb_median"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            pass
         wi0, _, win0 = h.get_state(0)
         out = {
             "metric": "accepted delta-moves/sec (whole node) at N_tau=64, N_delta=2000",
@@ -151,7 +159,8 @@ def main():
             "sweeps_per_s": sweeps / dt_max, "proposals_per_s": props / dt_max,
             "acceptance": {"evaluated_frac": evald / props, "accepted_moves_per_proposal": moves / props},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes per launch beyond L2, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json",
                          "kernel": "free_stage_kernel<1,false,true>", "launches": launches,
                          "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1)},
