@@ -39,7 +39,7 @@ struct FreeParams {
     const double *G;            // [128] zero padded
     const double *sinv;         // [128] zero padded
     uint32_t *wi;               // [n_chains][wi_stride] relative positions
-    const double *A;            // [n_chains][wi_stride] amplitudes (used when !uniform_A)
+    double *A;                  // [n_chains][wi_stride] amplitudes (read when !uniform_A; par=2 writes them back)
     double *gbar;               // [n_chains][128]
     ChainScalars *sc;           // [n_chains]
     double *hist;               // [hist_copies][n_grid]
@@ -56,7 +56,7 @@ struct FreeParams {
     uint32_t chain_offset, seed_lo, seed_hi;
     int uniform_A;
     int hist_copies, hist_exclusive, hist_mode;
-    int n_sweeps, flags, par;
+    int n_sweeps, flags, par, symm;
     int log_chain;
 };
 
@@ -344,6 +344,318 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
         }
     }
     return accepted;
+}
+
+// ------------------------------------------------------------------------------------------
+// par = 2 amplitude moves (free:483-570 A_w_move, free:674-728 double_A_move).  The chain's
+// amplitudes live in LDS (c.A points there) because they change during the launch.
+// ------------------------------------------------------------------------------------------
+
+struct DecodedAW {      // A_w_move: pair shift + amplitude transfer that conserves the first moment
+    int k[2], wold[2], wnew[2];
+    int sd, inb, dead;
+    double lnu, A[2], Ap[2];
+};
+
+__device__ __forceinline__ void aw_compute(DecodedAW &d, int gmax)
+{
+    d.wnew[0] = d.wold[0] + d.sd;                                   // free:501-507
+    d.wnew[1] = d.wold[1] - d.sd;
+    bool ok = !d.dead;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ok = ok && (d.wnew[q] >= 0) && (d.wnew[q] <= gmax);   // free:509-517
+    const int mag = d.sd < 0 ? -d.sd : d.sd;
+    // free:522  dA = dw (A1 - A2) / (2 dw + w1 - w2), dw the unsigned magnitude
+    const double dA = ((double)mag * (d.A[0] - d.A[1])) / (double)(2 * mag + d.wold[0] - d.wold[1]);
+    d.Ap[0] = d.A[0] + dA;
+    d.Ap[1] = d.A[1] - dA;
+    if (d.Ap[0] < 0 || d.Ap[1] < 0) ok = false;                     // free:528-532
+    d.inb = ok ? 1 : 0;
+}
+
+template <int DEPTH, int NTL, bool LOG>
+__device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, double window)
+{
+    constexpr int MOVE = 4;
+    int accepted = 0;
+    for (int base = 0; base < n_it; base += 64) {
+        const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
+        DecodedAW d;
+        {
+            const uint32_t iter = (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1));
+            const uint32_t c2 = c.sweep_hi | ((uint32_t)MOVE << 16);
+            const u32x4 b0 = philox4x32_10(iter, c.sweep_lo, c2, c.chain_id, c.key0, c.key1);
+            const u32x4 b1 = philox4x32_10(iter, c.sweep_lo, c2 | (1u << 24), c.chain_id, c.key0, c.key1);
+            const uint32_t n = (uint32_t)c.n_omega;
+            uint32_t retry = 2;
+            d.dead = 0;
+            d.k[0] = index_from_word(b0.x, n);
+            int k2 = index_from_word(b0.y, n);
+            while (k2 == d.k[0]) {                                  // free:495-497
+                if (retry > 255) { d.dead = 1; k2 = (d.k[0] + 1) % (int)n; break; }
+                const u32x4 br = philox4x32_10(iter, c.sweep_lo, c2 | (retry << 24), c.chain_id, c.key0, c.key1);
+                ++retry;
+                k2 = index_from_word(br.x, n);
+            }
+            d.k[1] = k2;
+            d.sd = shift_from_draw(u01(b0.z, b0.w), u01(b1.x, b1.y), window);   // free:499-507
+            d.lnu = log_u01(u01(b1.z, b1.w));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { d.wold[q] = (int)c.wi[d.k[q]]; d.A[q] = A[d.k[q]]; }
+            aw_compute(d, c.gmax);
+        }
+        double kn[DEPTH][2][NTL], ko[DEPTH][2][NTL];
+        int is_inb[DEPTH], is_old[DEPTH][2], is_new[DEPTH][2];
+        unsigned long long stale = 0ull;
+
+        auto issue = [&](auto U, int j) {
+            constexpr int u = decltype(U)::value;
+            const int jj = (j < cnt) ? j : cnt - 1;
+            const int inb = __builtin_amdgcn_readlane(d.inb, jj);
+            is_inb[u] = inb;
+            if (j < cnt) stale &= ~(1ull << j);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int o = __builtin_amdgcn_readlane(d.wold[q], jj);
+                const int nw = inb ? __builtin_amdgcn_readlane(d.wnew[q], jj) : o;
+                is_old[u][q] = o;
+                is_new[u][q] = nw;
+                load_col<NTL>(c, nw, kn[u][q]);
+                load_col<NTL>(c, o, ko[u][q]);
+            }
+        };
+        auto resolve = [&](auto U, int j) {
+            constexpr int u = decltype(U)::value;
+            int inb = is_inb[u];
+            int s_old[2], s_new[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { s_old[q] = is_old[u][q]; s_new[q] = is_new[u][q]; }
+            const bool was_stale = ((stale >> j) & 1ull) != 0ull;
+            if (was_stale) {
+                inb = __builtin_amdgcn_readlane(d.inb, j);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    s_old[q] = __builtin_amdgcn_readlane(d.wold[q], j);
+                    s_new[q] = __builtin_amdgcn_readlane(d.wnew[q], j);
+                }
+            }
+            int acc = 0;
+            double chi2_new = 0.0;
+            if (inb) {
+                double sA[2], sAp[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { sA[q] = readlane_f64(d.A[q], j); sAp[q] = readlane_f64(d.Ap[q], j); }
+                double fn[2][NTL], fo[2][NTL];
+                if (!was_stale) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int t = 0; t < NTL; ++t) { fn[q][t] = kn[u][q][t]; fo[q][t] = ko[u][q][t]; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { load_col<NTL>(c, s_new[q], fn[q]); load_col<NTL>(c, s_old[q], fo[q]); }
+                }
+                double gnew[NTL], term = 0.0;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {                       // free:535-541
+                    const double g = (((c.gbar[t] + (sAp[0] * fn[0][t])) + (sAp[1] * fn[1][t]))
+                                      - (sA[0] * fo[0][t])) - (sA[1] * fo[1][t]);
+                    gnew[t] = g;
+                    const double e = (g - c.G[t]) * c.sinv[t];
+                    const double e2 = e * e;
+                    term = (t == 0) ? e2 : (term + e2);
+                }
+                chi2_new = wave_sum_uniform(term);
+                acc = metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j)) ? 1 : 0;
+                c.n_eval += 1;
+                c.n_cols += 4;
+                if (acc) {                                            // free:548-561
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];
+                    c.chi2 = chi2_new;
+                    if (chi2_new < c.chi2_min) c.chi2_min = chi2_new;
+                    int s_k[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) s_k[q] = __builtin_amdgcn_readlane(d.k[q], j);
+                    if (c.lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) { c.wi[s_k[q]] = (uint32_t)s_new[q]; A[s_k[q]] = sAp[q]; }
+                    }
+                    accepted += 1;
+                    c.n_acc += 1;
+                    c.n_accmoves += 2;
+                    bool hit = false;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) hit = hit || (d.k[a] == s_k[b]);
+                    hit = hit && (c.lane > j);
+                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
+                    if (hits != 0ull) {
+                        stale |= hits;
+                        if (hit) {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) { d.wold[q] = (int)c.wi[d.k[q]]; d.A[q] = A[d.k[q]]; }
+                            aw_compute(d, c.gmax);
+                        }
+                    }
+                }
+            }
+            if constexpr (LOG) {
+                if (c.log != nullptr) {
+                    if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {
+                        MoveRec r;
+                        r.chi2_new = inb ? chi2_new : 0.0;
+                        r.flags = (inb ? 1 : 0) | (acc ? 2 : 0);
+                        r.move = MOVE;
+                        c.log[c.log_pos] = r;
+                    }
+                    c.log_pos += 1;
+                }
+            }
+        };
+        [&]<int... Us>(std::integer_sequence<int, Us...>) {
+            (issue(std::integral_constant<int, Us>{}, Us), ...);
+        }(std::make_integer_sequence<int, DEPTH>{});
+        for (int j0 = 0; j0 < cnt; j0 += DEPTH) {
+            [&]<int... Us>(std::integer_sequence<int, Us...>) {
+                (((j0 + Us < cnt) ? (resolve(std::integral_constant<int, Us>{}, j0 + Us), 0) : 0,
+                  issue(std::integral_constant<int, Us>{}, j0 + Us + DEPTH)), ...);
+            }(std::make_integer_sequence<int, DEPTH>{});
+        }
+    }
+    return accepted;
+}
+
+struct DecodedDA {      // double_A_move: re-split the weight of two deltas at different frequencies
+    int k[2], w[2];
+    int dead;
+    double r, lnu, dA[2];
+};
+
+__device__ __forceinline__ void da_compute(DecodedDA &d, const double *A)
+{
+    const double A1 = A[d.k[0]], A2 = A[d.k[1]];
+    const double m0 = A1 + A2;                                      // free:688
+    d.dA[0] = (d.r * m0) - A1;                                      // free:692-693
+    d.dA[1] = ((1 - d.r) * m0) - A2;
+}
+
+template <int DEPTH, int NTL, bool LOG>
+__device__ __forceinline__ int da_move_loop(Chain<NTL> &c, double *A, int n_it)
+{
+    constexpr int MOVE = 5;
+    int accepted = 0;
+    for (int base = 0; base < n_it; base += 64) {
+        const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
+        DecodedDA d;
+        {
+            const uint32_t iter = (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1));
+            const uint32_t c2 = c.sweep_hi | ((uint32_t)MOVE << 16);
+            const u32x4 b0 = philox4x32_10(iter, c.sweep_lo, c2, c.chain_id, c.key0, c.key1);
+            const u32x4 b1 = philox4x32_10(iter, c.sweep_lo, c2 | (1u << 24), c.chain_id, c.key0, c.key1);
+            const uint32_t n = (uint32_t)c.n_omega;
+            uint32_t retry = 2;
+            d.dead = 0;
+            d.k[0] = index_from_word(b0.x, n);
+            d.w[0] = (int)c.wi[d.k[0]];
+            int k2 = index_from_word(b0.y, n);
+            int w2 = (int)c.wi[k2];
+            while (w2 == d.w[0]) {                                  // free:684-686 (by frequency)
+                if (retry > 255) { d.dead = 1; break; }
+                const u32x4 br = philox4x32_10(iter, c.sweep_lo, c2 | (retry << 24), c.chain_id, c.key0, c.key1);
+                ++retry;
+                k2 = index_from_word(br.x, n);
+                w2 = (int)c.wi[k2];
+            }
+            d.k[1] = k2;
+            d.w[1] = w2;
+            d.r = u01(b0.z, b0.w);
+            d.lnu = log_u01(u01(b1.x, b1.y));
+            da_compute(d, A);
+        }
+        // frequencies do not change in this loop: the prefetched columns never go stale
+        double k1[DEPTH][NTL], k2c[DEPTH][NTL];
+        auto issue = [&](auto U, int j) {
+            constexpr int u = decltype(U)::value;
+            const int jj = (j < cnt) ? j : cnt - 1;
+            load_col<NTL>(c, __builtin_amdgcn_readlane(d.w[0], jj), k1[u]);
+            load_col<NTL>(c, __builtin_amdgcn_readlane(d.w[1], jj), k2c[u]);
+        };
+        auto resolve = [&](auto U, int j) {
+            constexpr int u = decltype(U)::value;
+            const int live = !__builtin_amdgcn_readlane(d.dead, j);
+            int acc = 0;
+            double chi2_new = 0.0;
+            if (live) {
+                const double dA1 = readlane_f64(d.dA[0], j), dA2 = readlane_f64(d.dA[1], j);
+                double gnew[NTL], term = 0.0;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {                       // free:696-700
+                    const double g = (c.gbar[t] + (dA1 * k1[u][t])) + (dA2 * k2c[u][t]);
+                    gnew[t] = g;
+                    const double e = (g - c.G[t]) * c.sinv[t];
+                    const double e2 = e * e;
+                    term = (t == 0) ? e2 : (term + e2);
+                }
+                chi2_new = wave_sum_uniform(term);
+                acc = metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j)) ? 1 : 0;
+                c.n_eval += 1;
+                c.n_cols += 2;
+                if (acc) {                                            // free:707-718
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];
+                    c.chi2 = chi2_new;
+                    if (chi2_new < c.chi2_min) c.chi2_min = chi2_new;
+                    const int sk1 = __builtin_amdgcn_readlane(d.k[0], j), sk2 = __builtin_amdgcn_readlane(d.k[1], j);
+                    if (c.lane == 0) {
+                        A[sk1] = A[sk1] + dA1;                        // free:708-709 (+=)
+                        A[sk2] = A[sk2] + dA2;
+                    }
+                    accepted += 1;
+                    c.n_acc += 1;
+                    c.n_accmoves += 2;
+                    const bool hit = (c.lane > j) && (d.k[0] == sk1 || d.k[0] == sk2 || d.k[1] == sk1 || d.k[1] == sk2);
+                    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                        if (hit) da_compute(d, A);
+                    }
+                }
+            }
+            if constexpr (LOG) {
+                if (c.log != nullptr) {
+                    if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {
+                        MoveRec r;
+                        r.chi2_new = live ? chi2_new : 0.0;
+                        r.flags = (live ? 1 : 0) | (acc ? 2 : 0);
+                        r.move = MOVE;
+                        c.log[c.log_pos] = r;
+                    }
+                    c.log_pos += 1;
+                }
+            }
+        };
+        [&]<int... Us>(std::integer_sequence<int, Us...>) {
+            (issue(std::integral_constant<int, Us>{}, Us), ...);
+        }(std::make_integer_sequence<int, DEPTH>{});
+        for (int j0 = 0; j0 < cnt; j0 += DEPTH) {
+            [&]<int... Us>(std::integer_sequence<int, Us...>) {
+                (((j0 + Us < cnt) ? (resolve(std::integral_constant<int, Us>{}, j0 + Us), 0) : 0,
+                  issue(std::integral_constant<int, Us>{}, j0 + Us + DEPTH)), ...);
+            }(std::make_integer_sequence<int, DEPTH>{});
+        }
+    }
+    return accepted;
+}
+
+// A_array ./= sum(A_array) (x2 if symm), free:563-567, 721-725.  Sum order: lane l adds elements
+// l, l+64, ... sequentially, then the canonical tree.
+__device__ __forceinline__ void renormalise(double *A, int n, int symm, int lane)
+{
+    double part = 0.0;
+    for (int i = lane; i < n; i += 64) part = part + A[i];
+    double tot = wave_sum_uniform(part);
+    if (symm == 1) tot = 2 * tot;
+    for (int i = lane; i < n; i += 64) A[i] = A[i] / tot;
 }
 
 }  // namespace sacdev

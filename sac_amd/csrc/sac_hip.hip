@@ -23,13 +23,17 @@ using namespace sacdev;
 
 // One launch = n_sweeps sweeps (run_updates, free:825-861) of every chain, plus, by flag, the
 // per-sweep sampling work (free:918-919) and the end-of-round window retune (free:883-895).
-template <int NTL, bool LOG, bool UA>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(const FreeParams p)
+// PAR2 (amplitude updates, free:839-855): the amplitudes join the positions in LDS, two chains per block.
+template <int NTL, bool LOG, bool UA, bool PAR2>
+__global__ void __launch_bounds__(64 * (PAR2 ? 2 : WAVES_PER_BLOCK), PAR2 ? 2 : 4)
+free_stage_kernel(const FreeParams p)
 {
-    __shared__ uint32_t s_wi[WAVES_PER_BLOCK][MAX_N_OMEGA];
-    __shared__ double s_sc[WAVES_PER_BLOCK][12];   // windows[4], accept accumulators[6], sum chi2
+    constexpr int WPB = PAR2 ? 2 : WAVES_PER_BLOCK;
+    __shared__ uint32_t s_wi[WPB][MAX_N_OMEGA];
+    __shared__ double s_A[PAR2 ? WPB : 1][PAR2 ? MAX_N_OMEGA : 1];
+    __shared__ double s_sc[WPB][12];   // windows[4], accept accumulators[6], sum chi2
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int chain = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int chain = (int)blockIdx.x * WPB + wave;
     if (chain >= p.n_chains) return;
     const int lane = lane_id();
 
@@ -44,7 +48,12 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
     c.key0 = p.seed_lo;
     c.key1 = p.seed_hi;
     c.chain_id = p.chain_offset + (uint32_t)chain;
-    c.A = p.A + (size_t)chain * (size_t)p.wi_stride;
+    double *A_g = p.A + (size_t)chain * (size_t)p.wi_stride;
+    c.A = A_g;
+    if constexpr (PAR2) {
+        for (int i = lane; i < p.n_omega; i += 64) s_A[wave][i] = A_g[i];
+        c.A = s_A[wave];
+    }
     c.A_uniform = p.A_uniform;
     c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
     double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
@@ -98,6 +107,15 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
         a = move_loop<3, 3, D3, NTL, LOG, UA>(c, n / 3, 0.0);       // free:835-836
         if (lane == 0) acc[2] += (double)a / (double)(n / 3);
 #endif
+        if constexpr (PAR2) {
+            double *A = s_A[wave];
+            a = aw_move_loop<(NTL == 1) ? 4 : 2, NTL, LOG>(c, A, n / 2, win[3]);   // free:851-852
+            if (lane == 0) acc[3] += (double)(2 * a) / (double)(n / 2);
+            renormalise(A, n, p.symm, lane);                        // free:563-567
+            a = da_move_loop<(NTL == 1) ? 8 : 4, NTL, LOG>(c, A, n);               // free:854-855
+            if (lane == 0) acc[4] += (double)a / (double)n;
+            renormalise(A, n, p.symm, lane);                        // free:721-725
+        }
 #ifndef EXP_NOHIST
         if (p.flags & STAGE_SAMPLE) {
             if (p.hist_mode == SAC_HIST_REFERENCE) {
@@ -128,6 +146,9 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
     }
 
     for (int i = lane; i < p.n_omega; i += 64) wi_g[i] = c.wi[i];
+    if constexpr (PAR2) {
+        for (int i = lane; i < p.n_omega; i += 64) A_g[i] = s_A[wave][i];
+    }
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const int j = lane + 64 * t;
@@ -140,7 +161,8 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4) free_stage_kernel(con
         for (int k = 0; k < 6; ++k) scp->acc[k] = acc[k];
         scp->sum_chi2 = *sum_chi2;
         scp->sweep = sweep;
-        scp->counters[0] += (unsigned long long)p.n_sweeps * (unsigned long long)(n + n / 2 + n / 3);
+        scp->counters[0] += (unsigned long long)p.n_sweeps *
+                            (unsigned long long)(n + n / 2 + n / 3 + (PAR2 ? n / 2 + n : 0));
         scp->counters[1] += c.n_eval;
         scp->counters[2] += c.n_acc;
         scp->counters[3] += c.n_accmoves;
@@ -270,8 +292,8 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
     if (!cfg || !out) return fail(SAC_E_INVALID, "sac_create: null argument");
     *out = nullptr;
     if (cfg->kind != SAC_KIND_FREE) return fail(SAC_E_INVALID, "sac_create: unsupported kind %d", cfg->kind);
-    if (cfg->par != 1 && cfg->par != 3)
-        return fail(SAC_E_INVALID, "sac_create: par=%d not supported yet (1 and 3 are)", cfg->par);
+    if (cfg->par < 1 || cfg->par > 3)
+        return fail(SAC_E_INVALID, "sac_create: par=%d (1, 2 or 3)", cfg->par);
     if (cfg->n_tau < 1 || cfg->n_tau > SAC_MAX_N_TAU)
         return fail(SAC_E_INVALID, "sac_create: n_tau=%d outside 1..%d", cfg->n_tau, SAC_MAX_N_TAU);
     if (cfg->n_omega < 3 || cfg->n_omega > SAC_MAX_N_OMEGA)
@@ -474,6 +496,7 @@ static void fill_params(sac_handle *h, FreeParams &p)
     p.hist_copies = h->hist_copies; p.hist_exclusive = h->hist_exclusive ? 1 : 0;
     p.hist_mode = h->cfg.hist_mode;
     p.par = h->cfg.par;
+    p.symm = h->cfg.symm;
 }
 
 static unsigned grid_blocks(const sac_handle *h)
@@ -566,19 +589,28 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
             h->kev.emplace_back(a, b);
         }
         HIP_TRY(hipEventRecord(h->kev[li].first, h->stream));
-        const dim3 grid(grid_blocks(h)), block(64 * WAVES_PER_BLOCK);
-        const bool ua = h->uniform_A;
-        const int variant = (h->cfg.n_tau <= 64 ? 0 : 4) | (log ? 2 : 0) | (ua ? 1 : 0);
+        const bool par2 = (h->cfg.par == 2);
+        const bool ua = h->uniform_A && !par2;
+        const int wpb = par2 ? 2 : WAVES_PER_BLOCK;
+        const dim3 grid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), block(64 * wpb);
+        const int variant = (par2 ? 8 : 0) | (h->cfg.n_tau <= 64 ? 0 : 4) | (log ? 2 : 0) | (ua ? 1 : 0);
+#define SAC_LAUNCH(NTL_, LOG_, UA_, P2_) \
+    hipLaunchKernelGGL((free_stage_kernel<NTL_, LOG_, UA_, P2_>), grid, block, 0, h->stream, p)
         switch (variant) {
-        case 0: hipLaunchKernelGGL((free_stage_kernel<1, false, false>), grid, block, 0, h->stream, p); break;
-        case 1: hipLaunchKernelGGL((free_stage_kernel<1, false, true>), grid, block, 0, h->stream, p); break;
-        case 2: hipLaunchKernelGGL((free_stage_kernel<1, true, false>), grid, block, 0, h->stream, p); break;
-        case 3: hipLaunchKernelGGL((free_stage_kernel<1, true, true>), grid, block, 0, h->stream, p); break;
-        case 4: hipLaunchKernelGGL((free_stage_kernel<2, false, false>), grid, block, 0, h->stream, p); break;
-        case 5: hipLaunchKernelGGL((free_stage_kernel<2, false, true>), grid, block, 0, h->stream, p); break;
-        case 6: hipLaunchKernelGGL((free_stage_kernel<2, true, false>), grid, block, 0, h->stream, p); break;
-        default: hipLaunchKernelGGL((free_stage_kernel<2, true, true>), grid, block, 0, h->stream, p); break;
+        case 0: SAC_LAUNCH(1, false, false, false); break;
+        case 1: SAC_LAUNCH(1, false, true, false); break;
+        case 2: SAC_LAUNCH(1, true, false, false); break;
+        case 3: SAC_LAUNCH(1, true, true, false); break;
+        case 4: SAC_LAUNCH(2, false, false, false); break;
+        case 5: SAC_LAUNCH(2, false, true, false); break;
+        case 6: SAC_LAUNCH(2, true, false, false); break;
+        case 7: SAC_LAUNCH(2, true, true, false); break;
+        case 8: SAC_LAUNCH(1, false, false, true); break;
+        case 10: SAC_LAUNCH(1, true, false, true); break;
+        case 12: SAC_LAUNCH(2, false, false, true); break;
+        default: SAC_LAUNCH(2, true, false, true); break;
         }
+#undef SAC_LAUNCH
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
         h->last_launches += 1;

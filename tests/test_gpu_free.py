@@ -42,6 +42,12 @@ CASES = [
                                 symm=1, omega_m=8.0, d_omega=2e-3), 10.0, 20, 10),
     ("synth_ntau64_par3", dict(kind="synth", n_tau=64, n_omega=300, par=3, omega_m=8.0, d_omega=1e-3),
      2.0, 20, 10),
+    # par = 2: amplitude updates (A_w_move, double_A_move, renormalisation after each)
+    ("golden_ntau22_par2", dict(kind="golden", n_omega=60, par=2), 2.0, 40, 25),
+    ("synth_ntau64_par2", dict(kind="synth", n_tau=64, n_omega=700, par=2, omega_m=8.0, d_omega=1e-3),
+     1.0, 20, 8),
+    ("synth_ntau80_par2_symm", dict(kind="synth", n_tau=80, n_omega=150, par=2, kernel_type="finiteT",
+                                    symm=1, omega_m=6.0, d_omega=2e-3), 5.0, 20, 10),
 ]
 
 
@@ -58,6 +64,8 @@ def test_move_for_move_parity(name, kw, theta, n_adj, n_smp):
     h = prob.make_handle(n_chains=n_chains, seed=seed, chain_offset=7, hist_copies=n_chains,
                          sweeps_per_launch=7)
     per_sweep = prob.n_omega + prob.n_omega // 2 + prob.n_omega // 3
+    if prob.par == 2:
+        per_sweep += prob.n_omega // 2 + prob.n_omega
     n_sweeps = (n_adj // 10) * 10 + n_smp
     cap = per_sweep * n_sweeps
     h.set_move_log(log_chain, cap)
