@@ -296,3 +296,223 @@ class OracleFree:
         c = (C.c_uint64 * 4)()
         self.L.ora_free_get_counters(self.h, c)
         return [int(x) for x in c]
+
+
+# --------------------------------------------------------------------------
+# peak parameterisation ("peak:NNN" = sac/peak/sac_peak.jl line NNN)
+# --------------------------------------------------------------------------
+
+def _peak_lib():
+    L = lib()
+    if getattr(L, "_peak_ready", False):
+        return L
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_void_p
+    L.ora_peak_create.restype = vp
+    L.ora_peak_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                  C.c_int, dp, dp, dp, dp]
+    L.ora_peak_destroy.argtypes = [vp]
+    L.ora_peak_set_state.argtypes = [vp, ip, dp, dp]
+    L.ora_peak_get_state.argtypes = [vp, ip, dp, dp]
+    L.ora_peak_init.argtypes = [vp]
+    L.ora_peak_set_bounds.argtypes = [vp, dp]
+    L.ora_peak_get_bounds.argtypes = [vp, dp]
+    L.ora_peak_get_gbar.argtypes = [vp, dp, dp, dp]
+    L.ora_peak_use_philox.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64]
+    L.ora_peak_set_indiv_update.argtypes = [vp, C.c_int]
+    L.ora_peak_set_log.argtypes = [vp, vp, C.c_int64]
+    L.ora_peak_log_len.restype = C.c_int64
+    L.ora_peak_log_len.argtypes = [vp]
+    L.ora_peak_sweep_counter.restype = C.c_uint64
+    L.ora_peak_sweep_counter.argtypes = [vp]
+    L.ora_peak_run_updates.argtypes = [vp, C.c_double, C.c_int]
+    L.ora_peak_adjust_windows.argtypes = [vp, C.c_int64, C.c_double]
+    L.ora_peak_sample.argtypes = [vp, C.c_int64, C.c_double, C.c_int]
+    L.ora_peak_get_accept_rates.argtypes = [vp, dp]
+    L.ora_peak_sampled_chi2.restype = C.c_double
+    L.ora_peak_sampled_chi2.argtypes = [vp]
+    L.ora_peak_get_edge_res.argtypes = [vp, dp]
+    L.ora_peak_set_edge_res.argtypes = [vp, dp]
+    L.ora_peak_zero_spec.argtypes = [vp]
+    L.ora_peak_get_spec.argtypes = [vp, C.c_int, dp]
+    L.ora_peak_get_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L._peak_ready = True
+    return L
+
+
+def read_tin_peak(path, symm=0, kernel_type="finiteT"):
+    """peak:97-138 read_G!: as free's, but omega_window from tau <= beta/4 and the +/- peak weight
+    ratio guess G(tau_1)/G(tau_N) (peak:117-127)."""
+    t = read_tin(path)
+    tau, G, beta = t["tau"], t["G"], t["beta"]
+    q = tau <= (beta // 4)
+    t["omega_window"] = np.log(1.0 / G[q][-1]) / tau[q][-1]          # peak:117-119
+    if symm == 1 or kernel_type == "bosonic" or tau.max() <= beta // 2:
+        t["approx_ratio"] = np.inf                                   # peak:122-124
+    else:
+        t["approx_ratio"] = G[0] / G[-1]                             # peak:126
+    return t
+
+
+def initialize_peak(tin, n_omega, n_p, A_0, omega_m, d_omega, omega_0=0.0, fix_edge=0, symm=0,
+                    kernel_type="finiteT"):
+    """peak:149-285 initialize!.  Returns dict(wi0, wim, n_grid, wi, A, Kp, Kn, window)."""
+    wi0 = int(np.floor(omega_0 / d_omega))                           # peak:151
+    wim = int(np.ceil(omega_m / d_omega))
+    window = tin["omega_window"] / d_omega                           # peak:154
+    N, P = n_omega, n_p
+    wi = np.zeros(2 * (N + P), dtype=np.int64)
+    A = np.zeros(2 * (N + P))
+    pp, cp, pn, cn = slice(0, P), slice(P, P + N), slice(P + N, 2 * P + N), slice(2 * P + N, 2 * P + 2 * N)
+    r = tin["approx_ratio"]
+    inv_r = 0.0 if np.isinf(r) else 1.0 / r
+    A0_p = A_0 / (1 + inv_r)                                         # peak:172-173
+    A0_n = 0.0 if np.isinf(r) else A_0 / (1 + r)
+    start = int(np.floor(wi0)) if fix_edge == 1 else int(np.floor(window))   # peak:178-184
+    wi[pp] = start
+    wi[pn] = start
+    A[pp] = A0_p / P                                                 # peak:186-187
+    A[pn] = A0_n / P
+    wi_pp, wi_np = wi[pp].max(), wi[pn].max()
+    i = np.arange(1, N + 1)
+    spread = np.floor((window / N) * i).astype(np.int64)             # peak:198-199
+    wi[cp] = int(np.floor(wi_pp * 1.0)) + spread
+    wi[cn] = int(np.floor(wi_np * 1.0)) + spread
+    Ac_p = (1 - A_0) / (1 + inv_r)                                   # peak:207-208
+    Ac_n = 0.0 if np.isinf(r) else (1 - A_0) / (1 + r)
+    A[cp] = (i / i.sum()) * Ac_p                                     # peak:210-211
+    A[cn] = (i / i.sum()) * Ac_n
+    if symm == 1 or kernel_type == "bosonic":                        # peak:214-227
+        A[pp] = A_0 / P
+        A[cp] = (1 - A_0) / N
+        A[pn] = 0
+        A[cn] = 0
+        if symm == 1:
+            A = A / (2 * A.sum())
+        wi[pn] = 0
+        wi[cn] = 0
+    else:
+        A = A / A.sum()                                              # peak:229
+    n_grid = wim + 1
+    n_tau = tin["n_tau"]
+    Kp = np.zeros((n_grid, n_tau))
+    Kn = np.zeros((n_grid, n_tau))
+    U = tin["cov"]
+    for a in range(0, n_grid, 65536):
+        w = (np.arange(a, min(a + 65536, n_grid)) + 0.5) * d_omega   # peak:253 half-offset grid
+        kv = kernel_values(kernel_type, w, tin["tau"], tin["beta"])
+        if symm == 1:
+            kv = kv + kernel_values(kernel_type, -w, tin["tau"], tin["beta"])     # peak:258-262
+            Kp[a:a + len(w)] = kv @ U
+        else:
+            Kp[a:a + len(w)] = kv @ U                                # peak:265-266
+            if kernel_type != "bosonic":
+                Kn[a:a + len(w)] = kernel_values(kernel_type, -w, tin["tau"], tin["beta"]) @ U   # peak:270-272
+    return dict(wi0=wi0, wim=wim, n_grid=n_grid, wi=wi, A=A, Kp=Kp, Kn=Kn, window=window)
+
+
+class OraclePeak:
+    """One reference Markov chain of sac_peak.jl."""
+
+    def __init__(self, Kp, Kn, G, sigma_inv, n_omega, n_p, wi0, wim, symm=0, bosonic=0, fix_edge=0):
+        self.L = _peak_lib()
+        self.Kp = np.ascontiguousarray(Kp, dtype=np.float64)
+        self.Kn = np.ascontiguousarray(Kn, dtype=np.float64)
+        self.n_grid, self.n_tau = self.Kp.shape
+        self.n_omega, self.n_p = int(n_omega), int(n_p)
+        self.n_tot = 2 * (self.n_omega + self.n_p)
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        sigma_inv = np.ascontiguousarray(sigma_inv, dtype=np.float64)
+        self.h = self.L.ora_peak_create(self.n_tau, self.n_omega, self.n_p, int(wi0), int(wim), int(symm),
+                                        int(bosonic), int(fix_edge), _dp(self.Kp), _dp(self.Kn), _dp(G),
+                                        _dp(sigma_inv))
+        if not self.h:
+            raise ValueError("ora_peak_create failed")
+        self._log = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ora_peak_destroy(self.h)
+            self.h = None
+
+    def set_state(self, wi=None, A=None, windows=None):
+        wi = None if wi is None else np.ascontiguousarray(wi, dtype=np.int64)
+        A = None if A is None else np.ascontiguousarray(A, dtype=np.float64)
+        windows = None if windows is None else np.ascontiguousarray(windows, dtype=np.float64)
+        self.L.ora_peak_set_state(self.h, None if wi is None else _ip(wi), None if A is None else _dp(A),
+                                  None if windows is None else _dp(windows))
+
+    def get_state(self):
+        wi = np.empty(self.n_tot, dtype=np.int64)
+        A = np.empty(self.n_tot)
+        w = np.empty(11)
+        self.L.ora_peak_get_state(self.h, _ip(wi), _dp(A), _dp(w))
+        return wi, A, w
+
+    def init(self):
+        self.L.ora_peak_init(self.h)
+
+    def bounds(self):
+        b = np.empty(4)
+        self.L.ora_peak_get_bounds(self.h, _dp(b))
+        return b
+
+    def get_gbar(self):
+        g = np.empty(self.n_tau)
+        c, m = C.c_double(), C.c_double()
+        self.L.ora_peak_get_gbar(self.h, _dp(g), C.byref(c), C.byref(m))
+        return g, c.value, m.value
+
+    def use_philox(self, seed, chain, sweep0=0):
+        self.L.ora_peak_use_philox(self.h, seed, chain, sweep0)
+
+    def set_indiv_update(self, on):
+        self.L.ora_peak_set_indiv_update(self.h, int(on))
+
+    def enable_log(self, cap):
+        self._log = np.zeros(cap, dtype=MOVE_REC)
+        self.L.ora_peak_set_log(self.h, self._log.ctypes.data, cap)
+
+    def log(self):
+        return self._log[:min(self.L.ora_peak_log_len(self.h), len(self._log))]
+
+    def sweep_counter(self):
+        return self.L.ora_peak_sweep_counter(self.h)
+
+    def run_updates(self, theta, transfer=True):
+        self.L.ora_peak_run_updates(self.h, theta, int(transfer))
+
+    def adjust_windows(self, steps, theta):
+        self.L.ora_peak_adjust_windows(self.h, steps, theta)
+
+    def sample(self, steps, theta, bin=False):
+        self.L.ora_peak_sample(self.h, steps, theta, int(bin))
+
+    def accept_rates(self):
+        a = np.empty(11)
+        self.L.ora_peak_get_accept_rates(self.h, _dp(a))
+        return a
+
+    def sampled_chi2(self):
+        return self.L.ora_peak_sampled_chi2(self.h)
+
+    def edge_res(self):
+        e = np.empty(6)
+        self.L.ora_peak_get_edge_res(self.h, _dp(e))
+        return e.reshape(3, 2)
+
+    def set_edge_res(self, e):
+        e = np.ascontiguousarray(e, dtype=np.float64).reshape(6)
+        self.L.ora_peak_set_edge_res(self.h, _dp(e))
+
+    def zero_spec(self):
+        self.L.ora_peak_zero_spec(self.h)
+
+    def spec(self, which):
+        s = np.empty(self.n_grid)
+        self.L.ora_peak_get_spec(self.h, which, _dp(s))
+        return s
+
+    def counters(self):
+        c = (C.c_uint64 * 5)()
+        self.L.ora_peak_get_counters(self.h, c)
+        return [int(x) for x in c]

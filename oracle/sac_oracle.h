@@ -85,6 +85,34 @@ void ora_free_get_spec(const ora_free_t *s, double *out);  /* n_grid doubles */
  * [3] accepted delta-moves (accepted proposals weighted 1/2/3 deltas) */
 void ora_free_get_counters(const ora_free_t *s, uint64_t out[4]);
 
+/* ---- peak parameterisation (sac/peak/sac_peak.jl), see sac_oracle_peak.c --------------------- */
+typedef struct ora_peak ora_peak_t;
+ora_peak_t *ora_peak_create(int n_tau, int n_omega, int n_p, int64_t wi0, int64_t wim, int symm,
+                            int bosonic, int fix_edge, const double *Kp, const double *Kn,
+                            const double *G, const double *sigma_inv);
+void ora_peak_destroy(ora_peak_t *s);
+void ora_peak_set_state(ora_peak_t *s, const int64_t *wi, const double *A, const double *windows);
+void ora_peak_get_state(const ora_peak_t *s, int64_t *wi, double *A, double *windows);
+void ora_peak_init(ora_peak_t *s);
+void ora_peak_set_bounds(ora_peak_t *s, const double *b4);
+void ora_peak_get_bounds(const ora_peak_t *s, double *b4);
+void ora_peak_get_gbar(const ora_peak_t *s, double *gbar, double *chi2, double *chi2_min);
+void ora_peak_use_philox(ora_peak_t *s, uint64_t seed, uint32_t chain, uint64_t sweep0);
+void ora_peak_set_indiv_update(ora_peak_t *s, int on);
+void ora_peak_set_log(ora_peak_t *s, ora_move_rec_t *log, int64_t cap);
+int64_t ora_peak_log_len(const ora_peak_t *s);
+uint64_t ora_peak_sweep_counter(const ora_peak_t *s);
+void ora_peak_run_updates(ora_peak_t *s, double theta, int transfer);          /* peak:1006 */
+void ora_peak_adjust_windows(ora_peak_t *s, int64_t steps, double theta);      /* peak:1063 */
+void ora_peak_sample(ora_peak_t *s, int64_t steps, double theta, int bin);     /* peak:1100 */
+void ora_peak_get_accept_rates(const ora_peak_t *s, double out[11]);
+double ora_peak_sampled_chi2(const ora_peak_t *s);
+void ora_peak_get_edge_res(const ora_peak_t *s, double out[6]);
+void ora_peak_set_edge_res(ora_peak_t *s, const double in[6]);
+void ora_peak_zero_spec(ora_peak_t *s);
+void ora_peak_get_spec(const ora_peak_t *s, int which, double *out);
+void ora_peak_get_counters(const ora_peak_t *s, uint64_t out[5]);
+
 #ifdef __cplusplus
 }
 #endif
