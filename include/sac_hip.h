@@ -36,6 +36,7 @@ extern "C" {
 #define SAC_E_NOMEM      -4
 
 #define SAC_KIND_FREE     0   /* sac/free/sac_free.jl */
+#define SAC_KIND_PEAK     1   /* sac/peak/sac_peak.jl ("peak:NNN" = line NNN of that file) */
 
 #define SAC_HIST_REFERENCE  0 /* free:918 semantics: duplicate frequencies collapse, last delta wins */
 #define SAC_HIST_ACCUMULATE 1 /* every delta adds its amplitude */
@@ -63,7 +64,12 @@ typedef struct {
                                hist_copies == n_chains gives every chain a private replica
                                (plain read-modify-write, bit-reproducible). */
     int32_t  sweeps_per_launch; /* 0 = default; sweeps a single kernel launch runs */
-    int32_t  reserved;
+    /* SAC_KIND_PEAK only (0 otherwise).  n_omega is then N_omega, the continuum deltas per axis;
+     * a chain holds 2 (N_omega + N_p) deltas ordered peak+, cont+, peak-, cont- (peak:166-169),
+     * 11 windows (peak:63), and n_grid = wi_m + 1 columns per table (peak:248-249). */
+    int32_t  n_peak;        /* N_p (peak:9) */
+    int32_t  fix_edge;      /* peak:76 */
+    int32_t  bosonic;       /* kernel_type == :bosonic: only the positive axis is sampled (peak:1010) */
 } sac_config_t;
 
 typedef struct {
@@ -81,6 +87,21 @@ typedef struct {
     double   last_kernel_ms;   /* device time spent in the sweep kernel proper during it */
     int64_t  last_kernel_launches;
 } sac_stats_t;
+
+typedef struct {               /* SAC_KIND_PEAK: what sac_peak.jl's CSV writers print (peak:1301-1333, 1386-1421) */
+    double   sampled_chi2;     /* mean over chains */
+    double   chi2_min;         /* min over chains */
+    double   accept_rates[11]; /* peak:62, mean over chains */
+    double   windows[11];      /* peak:63, mean over chains */
+    double   edge_res[3][2];   /* peak:74,1159-1161: [0] mean edge of the last sample stage, [1] sum of
+                                  those means and [2] of their squares since sac_zero_accumulators;
+                                  columns: + axis, - axis; mean over chains */
+    double   bounds[4];        /* wi_pp, wi_pc, wi_np, wi_nc (peak:14-17), mean over chains */
+    double   weights[4];       /* sum of A over peak+, cont+, peak-, cont- (peak:1302-1311), mean over chains */
+    uint64_t proposals, evaluated, accepted, accepted_moves, sweeps, columns_gathered;
+    double   last_stage_ms, last_kernel_ms;
+    int64_t  last_kernel_launches;
+} sac_peak_stats_t;
 
 typedef struct {
     double  chi2_new;   /* chi^2 of the proposed configuration (0 when not evaluated) */
@@ -125,6 +146,26 @@ int sac_get_histogram(sac_handle_t *h, double *out);
 /* Same histogram as the un-normalised sum over this handle's chains, written to DEVICE memory
  * (e.g. a tensor handed to an RCCL all-reduce); *steps_times_chains receives the divisor. */
 int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, double *steps_times_chains);
+
+/* ---- SAC_KIND_PEAK ------------------------------------------------------------------------- */
+/* Kp_array / Kn_array of initialize! (peak:248-276), each [wi_m + 1][n_tau], tau contiguous; Kn may
+ * be NULL when only the positive axis is sampled (symm or bosonic). */
+int sac_upload_problem_peak(sac_handle_t *h, const double *Kp, const double *Kn, const double *G,
+                            const double *sigma_inv);
+/* sample(self, steps, theta, true): a bin of the final sampling -- histograms keep accumulating and
+ * the +/- weight transfer is off (peak:1100-1109). */
+int sac_sample_bin(sac_handle_t *h, int64_t steps, double theta);
+/* sac.indiv_update (peak:85, 1523) */
+int sac_set_indiv_update(sac_handle_t *h, int32_t on);
+/* edge_res .= 0; sampled_pspec .= 0; sampled_cspec .= 0 (peak:1370-1372) */
+int sac_zero_accumulators(sac_handle_t *h);
+int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out);
+/* sampled_pspec[:, pn] / sampled_cspec[:, pn] (peak:65-66): which = 0 peak+, 1 cont+, 2 peak-,
+ * 3 cont-.  Mean over chains; divided by the steps of the last sample stage (peak:1152-1153), or,
+ * after sac_sample_bin calls, the raw accumulated sums (the driver divides, peak:1380-1381). */
+int sac_get_histogram_peak(sac_handle_t *h, int32_t which, double *out);
+/* ωi_pp, ωi_pc, ωi_np, ωi_nc of one chain (peak:14-17) */
+int sac_get_bounds(sac_handle_t *h, int32_t chain, double *out4);
 
 /* Debug/parity: record every proposal of one chain (up to capacity) during the following stages. */
 int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);

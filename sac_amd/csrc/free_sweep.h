@@ -70,6 +70,9 @@ struct Chain {
     uint32_t col_bytes;         // bytes per (padded) column
     uint32_t *wi;               // LDS
     int lane, n_omega, gmax;
+    // what the current move loop draws from and where a delta may land (set per loop):
+    // index = k_first + rand(0..k_count-1); a new position p is allowed iff lo <= p <= hi
+    int k_first, k_count, lo, hi;
     uint32_t off[NTL];          // byte offset of this lane's tau slot(s), clamped into the column
     double gbar[NTL], G[NTL], sinv[NTL];
     double chi2, chi2_min, inv2theta;
@@ -110,7 +113,7 @@ struct Decoded {
 };
 
 template <int NCOL, bool UA>
-__device__ __forceinline__ void compute_new(Decoded<NCOL, UA> &d, int gmax)
+__device__ __forceinline__ void compute_new(Decoded<NCOL, UA> &d, int lo, int hi)
 {
     if constexpr (NCOL == 1) {
         d.wnew[0] = d.wold[0] + d.sd;                               // free:287-291
@@ -125,7 +128,7 @@ __device__ __forceinline__ void compute_new(Decoded<NCOL, UA> &d, int gmax)
     }
     bool ok = !d.dead;
 #pragma unroll
-    for (int c = 0; c < NCOL; ++c) ok = ok && (d.wnew[c] >= 0) && (d.wnew[c] <= gmax);  // free:293-297
+    for (int c = 0; c < NCOL; ++c) ok = ok && (d.wnew[c] >= lo) && (d.wnew[c] <= hi);  // free:293-297
     d.inb = ok ? 1 : 0;
 }
 
@@ -144,7 +147,7 @@ __device__ __forceinline__ void decode(const Chain<NTL> &c, int move, uint32_t i
     const uint32_t c2 = c.sweep_hi | ((uint32_t)move << 16);
     const u32x4 b0 = philox4x32_10(iter, c.sweep_lo, c2, c.chain_id, c.key0, c.key1);
     const u32x4 b1 = philox4x32_10(iter, c.sweep_lo, c2 | (1u << 24), c.chain_id, c.key0, c.key1);
-    const uint32_t n = (uint32_t)c.n_omega;
+    const uint32_t n = (uint32_t)c.k_count;
     uint32_t retry = 2;
     d.dead = 0;
     d.sd = 0;
@@ -180,10 +183,11 @@ __device__ __forceinline__ void decode(const Chain<NTL> &c, int move, uint32_t i
     }
 #pragma unroll
     for (int q = 0; q < NCOL; ++q) {
+        d.k[q] += c.k_first;
         d.wold[q] = (int)c.wi[d.k[q]];
         if constexpr (!UA) d.A[q] = c.A[d.k[q]];
     }
-    compute_new<NCOL, UA>(d, c.gmax);
+    compute_new<NCOL, UA>(d, c.lo, c.hi);
 }
 
 // A_c * (K[:, new] - K[:, old]) for every moved delta (free:301-302, 367-369, 448-451)
@@ -199,8 +203,8 @@ __device__ __forceinline__ void increments(const double (&A)[NCOL], const double
 
 // One move loop of a sweep: n_it proposals of NCOL simultaneous delta shifts.
 // Returns the number of accepted proposals.
-template <int NCOL, int MOVE, int DEPTH, int NTL, bool LOG, bool UA>
-__device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
+template <int NCOL, int DEPTH, int NTL, bool LOG, bool UA>
+__device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it, double window)
 {
     int accepted = 0;
     for (int base = 0; base < n_it; base += 64) {
@@ -310,7 +314,7 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, int n_it, double window)
                         if (hit) {
 #pragma unroll
                             for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];
-                            compute_new<NCOL, UA>(d, c.gmax);
+                            compute_new<NCOL, UA>(d, c.lo, c.hi);
                         }
                     }
                 }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <utility>
@@ -14,6 +15,7 @@
 #include "../../include/sac_hip.h"
 #include "free_sweep.h"
 #include "hist_sort.h"
+#include "peak_sweep.h"
 
 using namespace sacdev;
 
@@ -44,6 +46,7 @@ free_stage_kernel(const FreeParams p)
     c.lane = lane;
     c.n_omega = p.n_omega;
     c.gmax = p.gmax;
+    c.k_first = 0; c.k_count = p.n_omega; c.lo = 0; c.hi = p.gmax;
     c.inv2theta = p.inv2theta;
     c.key0 = p.seed_lo;
     c.key1 = p.seed_hi;
@@ -97,14 +100,14 @@ free_stage_kernel(const FreeParams p)
         int a;
         // prefetch depth per move type: two tau slots per lane double the ring's registers
         constexpr int D1 = (NTL == 1) ? 8 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
-        a = move_loop<1, 1, D1, NTL, LOG, UA>(c, n, win[0]);        // free:829-830
+        a = move_loop<1, D1, NTL, LOG, UA>(c, 1, n, win[0]);        // free:829-830
         if (lane == 0) acc[0] += (double)a / (double)n;
 #ifndef EXP_NO2
-        a = move_loop<2, 2, D2, NTL, LOG, UA>(c, n / 2, win[1]);    // free:832-833
+        a = move_loop<2, D2, NTL, LOG, UA>(c, 2, n / 2, win[1]);    // free:832-833
         if (lane == 0) acc[1] += (double)(2 * a) / (double)(n / 2);
 #endif
 #ifndef EXP_NO3
-        a = move_loop<3, 3, D3, NTL, LOG, UA>(c, n / 3, 0.0);       // free:835-836
+        a = move_loop<3, D3, NTL, LOG, UA>(c, 3, n / 3, 0.0);       // free:835-836
         if (lane == 0) acc[2] += (double)a / (double)(n / 3);
 #endif
         if constexpr (PAR2) {
@@ -219,6 +222,269 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) init_gbar_kernel(const F
     }
 }
 
+// ---- peak parameterisation -------------------------------------------------------------------
+// One launch = n_sweeps sweeps of sac_peak.jl's run_updates (peak:1006-1059) with the per-sweep
+// from-scratch refresh of Gbar/chi2 (peak:1072-1073, 1120-1121), by flag the sampling work
+// (peak:1126-1147) and the window retune (peak:1079-1091).  XFER: the amplitudes change (weight
+// transfer between the axes), so they live in LDS and a block holds two chains.
+enum : int { STAGE_BOUNDS_AT_START = 8 };
+
+template <int NTL, bool LOG, bool XFER>
+__global__ void __launch_bounds__(64 * (XFER ? 2 : WAVES_PER_BLOCK), XFER ? 2 : 4)
+peak_stage_kernel(const PeakParams pp)
+{
+    constexpr int WPB = XFER ? 2 : WAVES_PER_BLOCK;
+    const FreeParams &p = pp.f;
+    __shared__ uint32_t s_wi[WPB][MAX_N_OMEGA];
+    __shared__ double s_A[XFER ? WPB : 1][XFER ? MAX_N_OMEGA : 1];
+    __shared__ double s_sc[WPB][26];   // windows[11], accept accumulators[11], sum chi2, edge sums[2]
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chain = (int)blockIdx.x * WPB + wave;
+    if (chain >= p.n_chains) return;
+    const int lane = lane_id();
+    const int n_p = pp.n_p, n = pp.n_cont;
+    const int n_used = pp.sample_neg ? 2 * (n_p + n) : (n_p + n);
+    const char *Kp = reinterpret_cast<const char *>(p.K), *Kn = reinterpret_cast<const char *>(pp.Kn);
+
+    Chain<NTL> c;
+    c.Kb = Kp;
+    c.col_bytes = (uint32_t)p.ntp * 8u;
+    c.wi = s_wi[wave];
+    c.lane = lane;
+    c.n_omega = n;
+    c.gmax = pp.wim;
+    c.inv2theta = p.inv2theta;
+    c.key0 = p.seed_lo;
+    c.key1 = p.seed_hi;
+    c.chain_id = p.chain_offset + (uint32_t)chain;
+    double *A_g = p.A + (size_t)chain * (size_t)p.wi_stride;
+    double *A = A_g;
+    if constexpr (XFER) {
+        for (int i = lane; i < n_used; i += 64) s_A[wave][i] = A_g[i];
+        A = s_A[wave];
+    }
+    c.A = A;
+    c.A_uniform = 0.0;
+    c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
+    unsigned long long n_prop = 0;
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        c.off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        c.gbar[t] = gbar_g[j];
+        c.G[t] = p.G[j];
+        c.sinv[t] = p.sinv[j];
+    }
+    uint32_t *wi_g = p.wi + (size_t)chain * (size_t)p.wi_stride;
+    for (int i = lane; i < n_used; i += 64) c.wi[i] = wi_g[i];
+
+    PeakScalars *scp = pp.psc + chain;
+    c.chi2 = scp->chi2;
+    c.chi2_min = scp->chi2_min;
+    double *win = s_sc[wave], *acc = s_sc[wave] + 11, *sum_chi2 = s_sc[wave] + 22, *edge = s_sc[wave] + 23;
+    const bool zero = (p.flags & STAGE_ZERO_ACC) != 0;
+    if (lane < 11) { win[lane] = scp->windows[lane]; acc[lane] = zero ? 0.0 : scp->acc[lane]; }
+    if (lane == 0) *sum_chi2 = zero ? 0.0 : scp->sum_chi2;
+    if (lane < 2) edge[lane] = zero ? 0.0 : scp->edge_sum[lane];
+    unsigned long long sweep = scp->sweep;
+    int b_pp = scp->bounds[0], b_pc = scp->bounds[1], b_np = scp->bounds[2], b_nc = scp->bounds[3];
+    c.log = nullptr;
+    c.log_cap = 0;
+    c.log_pos = 0;
+    if constexpr (LOG) {
+        if (chain == p.log_chain) { c.log = p.log; c.log_cap = p.log_cap; c.log_pos = *p.log_len; }
+    }
+    double *hist = p.hist + (size_t)(chain % p.hist_copies) * 4 * (size_t)p.n_grid;
+    const int f_pp = 0, f_cp = n_p, f_pn = n_p + n, f_cn = 2 * n_p + n;
+    const int wi0 = pp.wi0, wim = pp.wim;
+    auto imax = [](int a, int b) { return a > b ? a : b; };
+    auto imin = [](int a, int b) { return a < b ? a : b; };
+
+    if (p.flags & STAGE_BOUNDS_AT_START) {                           // peak:1115-1116
+        b_pp = group_max(c.wi, f_pp, n_p, lane);
+        if (pp.sample_neg) b_np = group_max(c.wi, f_pn, n_p, lane);
+    }
+    constexpr int D1 = (NTL == 1) ? 8 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
+    for (int s = 0; s < p.n_sweeps; ++s) {
+        c.sweep_lo = (uint32_t)sweep;
+        c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
+        peak_refresh_gbar<NTL>(c, Kp, Kn, A, n_p, n, pp.sample_neg);
+        if (pp.refresh_bounds) {                                     // peak:1074-1075
+            b_pp = group_max(c.wi, f_pp, n_p, lane);
+            if (pp.sample_neg) b_np = group_max(c.wi, f_pn, n_p, lane);
+        }
+        int a;
+        if constexpr (XFER) {
+            if (pp.transfer && pp.sample_neg) {                      // peak:1018-1034
+                if (pp.indiv_update) {
+                    XferSpec<1> sp;
+                    sp.move_id = 19;                                 // cont_Aw_transfer, peak:706-792
+                    sp.first[0] = f_cp; sp.count[0] = n; sp.first[1] = f_cn; sp.count[1] = n;
+                    sp.lo[0] = imax(wi0, b_pp); sp.hi[0] = wim;
+                    sp.lo[1] = imax(wi0, b_pp); sp.hi[1] = wim;     // sic: peak:738 tests wi_pp on the n side
+                    sp.window[0] = win[5];
+                    a = xfer_loop<1, (NTL == 1) ? 4 : 2, NTL, LOG>(c, Kp, Kn, A, sp, n / 2);
+                    n_prop += n / 2;
+                    if (lane == 0) acc[5] += (double)a / (double)(n / 2);
+                    b_pc = group_min(c.wi, f_cp, n, lane);           // peak:787-788
+                    b_nc = group_min(c.wi, f_cn, n, lane);
+                    sp.move_id = 20;                                 // peak_Aw_transfer, peak:798-880
+                    sp.first[0] = f_pp; sp.count[0] = n_p; sp.first[1] = f_pn; sp.count[1] = n_p;
+                    sp.lo[0] = wi0; sp.hi[0] = imin(b_pc, wim);
+                    sp.lo[1] = wi0; sp.hi[1] = imin(b_nc, wim);
+                    sp.window[0] = win[6];
+                    a = xfer_loop<1, (NTL == 1) ? 4 : 2, NTL, LOG>(c, Kp, Kn, A, sp, 10);
+                    n_prop += 10;
+                    if (lane == 0) acc[6] += (double)a / 10.0;
+                    b_pp = group_max(c.wi, f_pp, n_p, lane);         // peak:876-877
+                    b_np = group_max(c.wi, f_pn, n_p, lane);
+                }
+                XferSpec<2> sp;                                      // Aw_transfer, peak:882-996
+                sp.move_id = 21;
+                sp.first[0] = f_cp; sp.count[0] = n; sp.first[1] = f_cn; sp.count[1] = n;
+                sp.first[2] = f_pp; sp.count[2] = n_p; sp.first[3] = f_pn; sp.count[3] = n_p;
+                sp.lo[0] = imax(wi0, b_pp); sp.hi[0] = wim;          // peak:918
+                sp.lo[1] = imax(wi0, b_np); sp.hi[1] = wim;          // peak:921
+                sp.lo[2] = wi0; sp.hi[2] = imin(b_pc, wim);          // peak:929
+                sp.lo[3] = wi0; sp.hi[3] = imin(b_nc, wim);          // peak:932
+                sp.window[0] = win[10]; sp.window[1] = win[10];
+                a = xfer_loop<2, 2, NTL, LOG>(c, Kp, Kn, A, sp, n / 2);
+                n_prop += n / 2;
+                if (lane == 0) acc[10] += (double)a / (double)(n / 2);
+            }
+        }
+        for (int pn = 1; pn <= (pp.sample_neg ? 2 : 1); ++pn) {      // peak:1037-1047
+            const int o7 = (pn - 1) * 7;
+            c.Kb = (pn == 1) ? Kp : Kn;
+            c.k_first = (pn == 1) ? f_cp : f_cn;
+            c.k_count = n;
+            c.lo = ((pn == 1) ? b_pp : b_np) + 1;                    // new <= floor(w_b): continue (peak:409)
+            c.hi = wim;
+            a = move_loop<1, D1, NTL, LOG, false>(c, 11 + pn - 1, n, win[0 + o7]);
+            if (lane == 0) acc[0 + o7] += (double)a / (double)n;
+            a = move_loop<2, D2, NTL, LOG, false>(c, 13 + pn - 1, n / 2, win[1 + o7]);
+            if (lane == 0) acc[1 + o7] += (double)(2 * a) / (double)(n / 2);
+            a = move_loop<3, D3, NTL, LOG, false>(c, 15 + pn - 1, n / 3, 0.0);
+            if (lane == 0) acc[2 + o7] += (double)a / (double)(n / 3);
+            n_prop += n + n / 2 + n / 3;
+            const int m = group_min(c.wi, c.k_first, n, lane);       // peak:440-444
+            if (pn == 1) b_pc = m; else b_nc = m;
+        }
+        if (pp.fix_edge != 1) {                                      // peak:1048-1056
+            for (int pn = 1; pn <= (pp.sample_neg ? 2 : 1); ++pn) {
+                c.Kb = (pn == 1) ? Kp : Kn;
+                c.k_first = (pn == 1) ? f_pp : f_pn;
+                c.k_count = n_p;
+                c.lo = wi0;                                          // peak:659-663
+                c.hi = (pn == 1) ? b_pc : b_nc;
+                a = move_loop<1, D1, NTL, LOG, false>(c, 17 + pn - 1, 10 * n_p, win[pn == 1 ? 3 : 4]);
+                if (lane == 0) acc[pn == 1 ? 3 : 4] += (double)a / (double)(10 * n_p);
+                n_prop += 10 * n_p;
+                const int m = group_max(c.wi, c.k_first, n_p, lane); // peak:693-697
+                if (pn == 1) b_pp = m; else b_np = m;
+            }
+        }
+        if (p.flags & STAGE_SAMPLE) {
+            for (int i = lane; i < n_used; i += 64) {                // peak:1126-1140
+                const int which = (i >= f_cn) ? 3 : (i >= f_pn) ? 2 : (i >= f_cp) ? 1 : 0;
+                unsafeAtomicAdd(&hist[(size_t)which * (size_t)p.n_grid + c.wi[i]], A[i]);
+            }
+            b_pp = group_max(c.wi, f_pp, n_p, lane);                 // peak:1142-1143
+            if (pp.sample_neg) b_np = group_max(c.wi, f_pn, n_p, lane);
+            if (lane == 0) {
+                *sum_chi2 += c.chi2;                                 // peak:1145-1147
+                edge[0] += (double)b_pp;
+                edge[1] += (double)b_np;
+            }
+        }
+        sweep += 1;
+    }
+
+    if ((p.flags & STAGE_RETUNE) && lane == 0) {                     // peak:1079-1091
+        for (int k = 0; k < 11; ++k) acc[k] = acc[k] / p.retune_div;
+        for (int k = 0; k < 11; ++k) {
+            if (acc[k] > 0.55) win[k] *= 1.2;
+            else if (acc[k] < 0.45) win[k] /= 1.2;
+        }
+    }
+    for (int i = lane; i < n_used; i += 64) wi_g[i] = c.wi[i];
+    if constexpr (XFER) {
+        for (int i = lane; i < n_used; i += 64) A_g[i] = s_A[wave][i];
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        if (j < p.n_tau) gbar_g[j] = c.gbar[t];
+    }
+    if (lane == 0) {
+        scp->chi2 = c.chi2;
+        scp->chi2_min = c.chi2_min;
+        for (int k = 0; k < 11; ++k) { scp->windows[k] = win[k]; scp->acc[k] = acc[k]; }
+        scp->sum_chi2 = *sum_chi2;
+        scp->edge_sum[0] = edge[0];
+        scp->edge_sum[1] = edge[1];
+        scp->sweep = sweep;
+        scp->bounds[0] = b_pp; scp->bounds[1] = b_pc; scp->bounds[2] = b_np; scp->bounds[3] = b_nc;
+        scp->counters[0] += n_prop;
+        scp->counters[1] += c.n_eval;
+        scp->counters[2] += c.n_acc;
+        scp->counters[3] += c.n_accmoves;
+        scp->counters[4] += c.n_cols;
+        if constexpr (LOG) {
+            if (c.log != nullptr) *p.log_len = c.log_pos;
+        }
+    }
+}
+
+// peak:1503-1506 and the bounds initialize! leaves (peak:190-191, 202-203)
+template <int NTL>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const PeakParams pp)
+{
+    const FreeParams &p = pp.f;
+    __shared__ uint32_t s_wi[WAVES_PER_BLOCK][MAX_N_OMEGA];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int chain = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (chain >= p.n_chains) return;
+    const int lane = lane_id();
+    const int n_p = pp.n_p, n = pp.n_cont;
+    const int n_used = pp.sample_neg ? 2 * (n_p + n) : (n_p + n);
+    Chain<NTL> c;
+    c.Kb = reinterpret_cast<const char *>(p.K);
+    c.col_bytes = (uint32_t)p.ntp * 8u;
+    c.wi = s_wi[wave];
+    c.lane = lane;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        c.off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        c.G[t] = p.G[j];
+        c.sinv[t] = p.sinv[j];
+    }
+    const uint32_t *wi_g = p.wi + (size_t)chain * (size_t)p.wi_stride;
+    for (int i = lane; i < n_used; i += 64) c.wi[i] = wi_g[i];
+    const double *A = p.A + (size_t)chain * (size_t)p.wi_stride;
+    peak_refresh_gbar<NTL>(c, c.Kb, reinterpret_cast<const char *>(pp.Kn), A, n_p, n, pp.sample_neg);
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        gbar_g[j] = (j < p.n_tau) ? c.gbar[t] : 0.0;
+    }
+    const int b_pp = group_max(c.wi, 0, n_p, lane), b_pc = group_min(c.wi, n_p, n, lane);
+    int b_np = 0, b_nc = 0;
+    if (pp.sample_neg) {
+        b_np = group_max(c.wi, n_p + n, n_p, lane);
+        b_nc = group_min(c.wi, 2 * n_p + n, n, lane);
+    }
+    if (lane == 0) {
+        PeakScalars *scp = pp.psc + chain;
+        scp->chi2 = c.chi2;
+        scp->chi2_min = c.chi2;
+        scp->bounds[0] = b_pp; scp->bounds[1] = b_pc; scp->bounds[2] = b_np; scp->bounds[3] = b_nc;
+    }
+}
+
 // chi^2 of a given Gbar (sac_set_gbar consistency helper is host side; this kernel sums replicas)
 __global__ void hist_sum_kernel(const double *hist, long long n_grid, int copies, double *dst)
 {
@@ -273,6 +539,18 @@ struct sac_handle {
     bool problem = false, state_set = false, gbar_set = false;
     bool uniform_A = false;
     double A_uniform = 0.0;
+    // layout of one chain's state as the caller sees it
+    bool peak = false;
+    int n_state = 0;               // positions / amplitudes per chain
+    int n_windows = 4;
+    int64_t pos_offset = 0;        // caller position - stored position
+    int hist_arrays = 1;
+    // peak only
+    double *dKn = nullptr;
+    PeakScalars *dPsc = nullptr;
+    double *dWeights = nullptr;    // [n_chains][4] group weight sums
+    bool sample_neg = false, indiv_update = false, binned = false;
+    std::vector<double> edge_rows; // [n_chains][3][2]: peak:74 edge_res per chain
     int last_stage = 0;            // 0 none, 1 adjust_windows, 2 sample
     int64_t last_steps = 0;
     double last_stage_ms = 0.0, last_kernel_ms = 0.0;
@@ -291,9 +569,20 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
 {
     if (!cfg || !out) return fail(SAC_E_INVALID, "sac_create: null argument");
     *out = nullptr;
-    if (cfg->kind != SAC_KIND_FREE) return fail(SAC_E_INVALID, "sac_create: unsupported kind %d", cfg->kind);
-    if (cfg->par < 1 || cfg->par > 3)
+    if (cfg->kind != SAC_KIND_FREE && cfg->kind != SAC_KIND_PEAK)
+        return fail(SAC_E_INVALID, "sac_create: unsupported kind %d", cfg->kind);
+    const bool peak = (cfg->kind == SAC_KIND_PEAK);
+    if (!peak && (cfg->par < 1 || cfg->par > 3))
         return fail(SAC_E_INVALID, "sac_create: par=%d (1, 2 or 3)", cfg->par);
+    const bool sample_neg = peak && !(cfg->symm == 1 || cfg->bosonic);
+    if (peak) {
+        if (cfg->n_peak < 1) return fail(SAC_E_INVALID, "sac_create: n_peak=%d", cfg->n_peak);
+        const long long used = (sample_neg ? 2ll : 1ll) * ((long long)cfg->n_omega + cfg->n_peak);
+        if (used > SAC_MAX_N_OMEGA)
+            return fail(SAC_E_INVALID, "sac_create: %lld sampled deltas per chain exceed %d", used, SAC_MAX_N_OMEGA);
+        if (cfg->wi_0 < 0 || cfg->n_grid != cfg->wi_m + 1)
+            return fail(SAC_E_INVALID, "sac_create: peak needs wi_0 >= 0 and n_grid == wi_m + 1");
+    }
     if (cfg->n_tau < 1 || cfg->n_tau > SAC_MAX_N_TAU)
         return fail(SAC_E_INVALID, "sac_create: n_tau=%d outside 1..%d", cfg->n_tau, SAC_MAX_N_TAU);
     if (cfg->n_omega < 3 || cfg->n_omega > SAC_MAX_N_OMEGA)
@@ -315,7 +604,13 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
     if (!h) return fail(SAC_E_NOMEM, "sac_create: out of host memory");
     h->cfg = *cfg;
     h->ntp = (cfg->n_tau + 7) / 8 * 8;
-    h->wi_stride = (cfg->n_omega + 63) / 64 * 64;
+    h->peak = peak;
+    h->sample_neg = sample_neg;
+    h->n_state = peak ? 2 * (cfg->n_omega + cfg->n_peak) : cfg->n_omega;
+    h->n_windows = peak ? 11 : 4;
+    h->pos_offset = peak ? 0 : cfg->wi_0;
+    h->hist_arrays = peak ? 4 : 1;
+    h->wi_stride = (h->n_state + 63) / 64 * 64;
     int copies = cfg->hist_copies;
     if (copies <= 0) copies = cfg->n_chains < 16 ? cfg->n_chains : 16;
     if (copies > cfg->n_chains) copies = cfg->n_chains;
@@ -343,7 +638,13 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
     ALLOC(h->dA, nc * h->wi_stride * sizeof(double));
     ALLOC(h->dGbar, nc * SAC_MAX_N_TAU * sizeof(double));
     ALLOC(h->dSc, nc * sizeof(ChainScalars));
-    ALLOC(h->dHist, (size_t)copies * (size_t)cfg->n_grid * sizeof(double));
+    ALLOC(h->dHist, (size_t)copies * (size_t)h->hist_arrays * (size_t)cfg->n_grid * sizeof(double));
+    if (peak) {
+        ALLOC(h->dKn, (size_t)cfg->n_grid * h->ntp * sizeof(double));
+        ALLOC(h->dPsc, nc * sizeof(PeakScalars));
+        ALLOC(h->dWeights, nc * 4 * sizeof(double));
+        h->edge_rows.assign(nc * 6, 0.0);
+    }
     ALLOC(h->dLogLen, sizeof(unsigned long long));
 #undef ALLOC
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
@@ -363,6 +664,7 @@ extern "C" int sac_destroy(sac_handle_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->dK); hipFree(h->dG); hipFree(h->dSinv); hipFree(h->dWi); hipFree(h->dA);
     hipFree(h->dGbar); hipFree(h->dSc); hipFree(h->dHist); hipFree(h->dLog); hipFree(h->dLogLen);
+    hipFree(h->dKn); hipFree(h->dPsc); hipFree(h->dWeights);
     for (auto &pr : h->kev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -408,14 +710,15 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
     int first, count, rc;
     if ((rc = chain_range(h, chain, &first, &count, "sac_set_state"))) return rc;
     if ((rc = use_device(h))) return rc;
-    const int n = h->cfg.n_omega;
+    const int n = h->n_state;
     if (wi) {
         std::vector<uint32_t> rel((size_t)h->wi_stride, 0u);
+        const int64_t lowest = h->peak ? 0 : h->cfg.wi_0;
         for (int i = 0; i < n; ++i) {
-            if (wi[i] < h->cfg.wi_0 || wi[i] > h->cfg.wi_m)
+            if (wi[i] < lowest || wi[i] > h->cfg.wi_m)
                 return fail(SAC_E_INVALID, "sac_set_state: omega_i[%d]=%lld outside [%lld,%lld]", i,
-                            (long long)wi[i], (long long)h->cfg.wi_0, (long long)h->cfg.wi_m);
-            rel[i] = (uint32_t)(wi[i] - h->cfg.wi_0);
+                            (long long)wi[i], (long long)lowest, (long long)h->cfg.wi_m);
+            rel[i] = (uint32_t)(wi[i] - h->pos_offset);
         }
         std::vector<uint32_t> all((size_t)count * (size_t)h->wi_stride);
         for (int c = 0; c < count; ++c)
@@ -444,7 +747,13 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
             h->uniform_A = false;
         }
     }
-    if (windows) {
+    if (windows && h->peak) {
+        std::vector<PeakScalars> sc((size_t)count);
+        HIP_TRY(hipMemcpy(sc.data(), h->dPsc + first, (size_t)count * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+        for (auto &s : sc)
+            for (int k = 0; k < 11; ++k) s.windows[k] = windows[k];
+        HIP_TRY(hipMemcpy(h->dPsc + first, sc.data(), (size_t)count * sizeof(PeakScalars), hipMemcpyHostToDevice));
+    } else if (windows) {
         std::vector<ChainScalars> sc((size_t)count);
         HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, (size_t)count * sizeof(ChainScalars), hipMemcpyDeviceToHost));
         for (auto &s : sc)
@@ -462,16 +771,20 @@ extern "C" int sac_get_state(sac_handle_t *h, int32_t chain, int64_t *wi, double
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    const int n = h->cfg.n_omega;
+    const int n = h->n_state;
     if (wi) {
         std::vector<uint32_t> rel((size_t)n);
         HIP_TRY(hipMemcpy(rel.data(), h->dWi + (size_t)chain * h->wi_stride, (size_t)n * sizeof(uint32_t),
                           hipMemcpyDeviceToHost));
-        for (int i = 0; i < n; ++i) wi[i] = (int64_t)rel[i] + h->cfg.wi_0;
+        for (int i = 0; i < n; ++i) wi[i] = (int64_t)rel[i] + h->pos_offset;
     }
     if (A)
         HIP_TRY(hipMemcpy(A, h->dA + (size_t)chain * h->wi_stride, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (windows) {
+    if (windows && h->peak) {
+        PeakScalars s;
+        HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 11; ++k) windows[k] = s.windows[k];
+    } else if (windows) {
         ChainScalars s;
         HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
         for (int k = 0; k < 4; ++k) windows[k] = s.windows[k];
@@ -504,6 +817,11 @@ static unsigned grid_blocks(const sac_handle *h)
     return (unsigned)((h->cfg.n_chains + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
 }
 
+static int peak_init(sac_handle *h);
+static int peak_adjust_windows(sac_handle *h, int64_t steps, double theta);
+static int peak_sample(sac_handle *h, int64_t steps, double theta, bool bin);
+static int peak_chain_stats(sac_handle *h, int32_t chain, double *out6, double *accept_rates);
+
 extern "C" int sac_init_gbar(sac_handle_t *h)
 {
     if (!h) return fail(SAC_E_INVALID, "sac_init_gbar: null handle");
@@ -511,6 +829,7 @@ extern "C" int sac_init_gbar(sac_handle_t *h)
         return fail(SAC_E_STATE, "sac_init_gbar: upload the problem and set the state first");
     int rc;
     if ((rc = use_device(h))) return rc;
+    if (h->peak) return peak_init(h);
     FreeParams p;
     fill_params(h, p);
     if (h->cfg.n_tau <= 64)
@@ -534,6 +853,13 @@ extern "C" int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double
     if (gbar)
         HIP_TRY(hipMemcpy(gbar, h->dGbar + (size_t)chain * SAC_MAX_N_TAU, (size_t)h->cfg.n_tau * sizeof(double),
                           hipMemcpyDeviceToHost));
+    if (h->peak) {
+        PeakScalars s;
+        HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        if (chi2) *chi2 = s.chi2;
+        if (chi2_min) *chi2_min = s.chi2_min;
+        return SAC_OK;
+    }
     ChainScalars s;
     HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
     if (chi2) *chi2 = s.chi2;
@@ -544,6 +870,7 @@ extern "C" int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double
 extern "C" int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, double chi2, double chi2_min)
 {
     if (!h || !gbar) return fail(SAC_E_INVALID, "sac_set_gbar: null argument");
+    if (h->peak) return fail(SAC_E_INVALID, "sac_set_gbar: peak refreshes Gbar itself every sweep (peak:1072)");
     int first, count, rc;
     if ((rc = chain_range(h, chain, &first, &count, "sac_set_gbar"))) return rc;
     if ((rc = use_device(h))) return rc;
@@ -653,10 +980,301 @@ static int stage_end(sac_handle *h, int kind, int64_t steps)
     return SAC_OK;
 }
 
+// ---- peak host side --------------------------------------------------------------------------
+
+// per-chain sums of A over the four groups (peak:1302-1311), lane-strided partials + tree
+__global__ void peak_weights_kernel(const double *A, int stride, int n_chains, int n_p, int n, double *out)
+{
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wave >= n_chains) return;
+    const int lane = lane_id();
+    const double *a = A + (size_t)wave * (size_t)stride;
+    const int first[4] = {0, n_p, n_p + n, 2 * n_p + n}, count[4] = {n_p, n, n_p, n};
+    for (int g = 0; g < 4; ++g) {
+        double part = 0.0;
+        for (int i = lane; i < count[g]; i += 64) part = part + a[first[g] + i];
+        const double tot = wave_sum_uniform(part);
+        if (lane == 0) out[(size_t)wave * 4 + g] = tot;
+    }
+}
+
+static void fill_peak_params(sac_handle *h, PeakParams &pp)
+{
+    fill_params(h, pp.f);
+    pp.f.gmax = (int)h->cfg.wi_m;
+    pp.Kn = h->dKn;
+    pp.psc = h->dPsc;
+    pp.n_p = h->cfg.n_peak;
+    pp.n_cont = h->cfg.n_omega;
+    pp.wi0 = (int)h->cfg.wi_0;
+    pp.wim = (int)h->cfg.wi_m;
+    pp.sample_neg = h->sample_neg ? 1 : 0;
+    pp.fix_edge = h->cfg.fix_edge;
+    pp.indiv_update = h->indiv_update ? 1 : 0;
+    pp.transfer = 1;
+    pp.refresh_bounds = 0;
+}
+
+extern "C" int sac_upload_problem_peak(sac_handle_t *h, const double *Kp, const double *Kn, const double *G,
+                                       const double *sigma_inv)
+{
+    if (!h || !h->peak) return fail(SAC_E_INVALID, "sac_upload_problem_peak: not a SAC_KIND_PEAK handle");
+    if (h->sample_neg && !Kn) return fail(SAC_E_INVALID, "sac_upload_problem_peak: Kn is required when both axes are sampled");
+    int rc = sac_upload_problem(h, Kp, G, sigma_inv);
+    if (rc) return rc;
+    if (Kn) {
+        const size_t nt = (size_t)h->cfg.n_tau, ng = (size_t)h->cfg.n_grid;
+        if ((size_t)h->ntp == nt) {
+            HIP_TRY(hipMemcpy(h->dKn, Kn, ng * nt * sizeof(double), hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy2D(h->dKn, (size_t)h->ntp * sizeof(double), Kn, nt * sizeof(double),
+                                nt * sizeof(double), ng, hipMemcpyHostToDevice));
+        }
+    }
+    return SAC_OK;
+}
+
+static int peak_init(sac_handle *h)
+{
+    PeakParams pp;
+    fill_peak_params(h, pp);
+    const dim3 grid(grid_blocks(h)), block(64 * WAVES_PER_BLOCK);
+    if (h->cfg.n_tau <= 64) hipLaunchKernelGGL(peak_init_kernel<1>, grid, block, 0, h->stream, pp);
+    else hipLaunchKernelGGL(peak_init_kernel<2>, grid, block, 0, h->stream, pp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->gbar_set = true;
+    return SAC_OK;
+}
+
+static int run_peak_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_all, int flags_first,
+                           int flags_last, double retune_div, bool transfer, bool refresh_bounds)
+{
+    PeakParams pp;
+    fill_peak_params(h, pp);
+    pp.f.inv2theta = 1.0 / (2.0 * theta);
+    pp.f.retune_div = retune_div;
+    pp.transfer = transfer ? 1 : 0;
+    pp.refresh_bounds = refresh_bounds ? 1 : 0;
+    const bool log = (h->log_chain >= 0 && h->dLog != nullptr);
+    int64_t done = 0;
+    bool first = true;
+    do {
+        int64_t chunk = n_sweeps - done;
+        if (chunk > h->sweeps_per_launch) chunk = h->sweeps_per_launch;
+        const bool last = (done + chunk >= n_sweeps);
+        pp.f.n_sweeps = (int)chunk;
+        pp.f.flags = flags_all | (first ? flags_first : 0) | (last ? flags_last : 0);
+        const size_t li = (size_t)h->last_launches;
+        if (h->kev.size() <= li) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            h->kev.emplace_back(a, b);
+        }
+        HIP_TRY(hipEventRecord(h->kev[li].first, h->stream));
+        const bool xfer = h->sample_neg;
+        const int wpb = xfer ? 2 : WAVES_PER_BLOCK;
+        const dim3 grid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), block(64 * wpb);
+        const int variant = (xfer ? 4 : 0) | (h->cfg.n_tau <= 64 ? 0 : 2) | (log ? 1 : 0);
+#define SAC_PLAUNCH(NTL_, LOG_, X_) \
+    hipLaunchKernelGGL((peak_stage_kernel<NTL_, LOG_, X_>), grid, block, 0, h->stream, pp)
+        switch (variant) {
+        case 0: SAC_PLAUNCH(1, false, false); break;
+        case 1: SAC_PLAUNCH(1, true, false); break;
+        case 2: SAC_PLAUNCH(2, false, false); break;
+        case 3: SAC_PLAUNCH(2, true, false); break;
+        case 4: SAC_PLAUNCH(1, false, true); break;
+        case 5: SAC_PLAUNCH(1, true, true); break;
+        case 6: SAC_PLAUNCH(2, false, true); break;
+        default: SAC_PLAUNCH(2, true, true); break;
+        }
+#undef SAC_PLAUNCH
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
+        h->last_launches += 1;
+        done += chunk;
+        first = false;
+    } while (done < n_sweeps);
+    return SAC_OK;
+}
+
+static int peak_adjust_windows(sac_handle *h, int64_t steps, double theta)
+{
+    int rc;
+    const int64_t per = steps / 10;                                  // peak:1070
+    for (int round = 0; round < 10; ++round)                         // peak:1066-1093
+        if ((rc = run_peak_sweeps(h, per, theta, 0, STAGE_ZERO_ACC, STAGE_RETUNE, (double)per, true, true)))
+            return rc;
+    return stage_end(h, 1, steps);
+}
+
+static int peak_sample(sac_handle *h, int64_t steps, double theta, bool bin)
+{
+    int rc;
+    if (!bin) {                                                      // peak:1103-1106
+        HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * 4 * (size_t)h->cfg.n_grid * sizeof(double),
+                               h->stream));
+        h->binned = false;
+    } else {
+        h->binned = true;
+    }
+    if ((rc = run_peak_sweeps(h, steps, theta, STAGE_SAMPLE, STAGE_ZERO_ACC | STAGE_BOUNDS_AT_START, 0, 1.0,
+                              !bin, false)))
+        return rc;
+    if ((rc = stage_end(h, 2, steps))) return rc;
+    // peak:1159-1165: per-chain edge means, and the running sums of means and squares
+    const int nc = h->cfg.n_chains;
+    std::vector<PeakScalars> sc((size_t)nc);
+    HIP_TRY(hipMemcpy(sc.data(), h->dPsc, (size_t)nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+    for (int c = 0; c < nc; ++c) {
+        double *e = h->edge_rows.data() + (size_t)c * 6;
+        for (int pn = 0; pn < 2; ++pn) {
+            e[0 + pn] = sc[(size_t)c].edge_sum[pn] / (double)steps;
+            e[2 + pn] += e[0 + pn];
+            e[4 + pn] += e[0 + pn] * e[0 + pn];
+        }
+        if (!h->sample_neg) { e[1] = e[0]; e[3] = e[2]; e[5] = e[4]; }
+    }
+    return SAC_OK;
+}
+
+extern "C" int sac_sample_bin(sac_handle_t *h, int64_t steps, double theta)
+{
+    int rc;
+    if (!h || !h->peak) return fail(SAC_E_INVALID, "sac_sample_bin: not a SAC_KIND_PEAK handle");
+    if ((rc = stage_begin(h, "sac_sample_bin", steps, theta))) return rc;
+    return peak_sample(h, steps, theta, true);
+}
+
+extern "C" int sac_set_indiv_update(sac_handle_t *h, int32_t on)
+{
+    if (!h || !h->peak) return fail(SAC_E_INVALID, "sac_set_indiv_update: not a SAC_KIND_PEAK handle");
+    h->indiv_update = (on != 0);
+    return SAC_OK;
+}
+
+extern "C" int sac_zero_accumulators(sac_handle_t *h)
+{
+    if (!h || !h->peak) return fail(SAC_E_INVALID, "sac_zero_accumulators: not a SAC_KIND_PEAK handle");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * 4 * (size_t)h->cfg.n_grid * sizeof(double), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::fill(h->edge_rows.begin(), h->edge_rows.end(), 0.0);
+    h->binned = true;
+    return SAC_OK;
+}
+
+static int peak_chain_stats(sac_handle *h, int32_t chain, double *out6, double *accept_rates)
+{
+    if (chain < 0 || chain >= h->cfg.n_chains)
+        return fail(SAC_E_INVALID, "sac_get_chain_stats: chain %d outside 0..%d", chain, h->cfg.n_chains - 1);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    PeakScalars s;
+    HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    const double steps = (double)h->last_steps;
+    if (out6) {
+        out6[0] = (h->last_stage == 2) ? s.sum_chi2 / steps : 0.0;
+        out6[1] = s.chi2;
+        out6[2] = s.chi2_min;
+        out6[3] = (double)s.sweep;
+        out6[4] = h->edge_rows[(size_t)chain * 6 + 0];
+        out6[5] = h->edge_rows[(size_t)chain * 6 + 1];
+    }
+    if (accept_rates)       // 11 entries for peak
+        for (int k = 0; k < 11; ++k) accept_rates[k] = (h->last_stage == 2) ? s.acc[k] / steps : s.acc[k];
+    return SAC_OK;
+}
+
+extern "C" int sac_get_bounds(sac_handle_t *h, int32_t chain, double *out4)
+{
+    if (!h || !h->peak || !out4) return fail(SAC_E_INVALID, "sac_get_bounds: not a SAC_KIND_PEAK handle");
+    if (chain < 0 || chain >= h->cfg.n_chains)
+        return fail(SAC_E_INVALID, "sac_get_bounds: chain %d outside 0..%d", chain, h->cfg.n_chains - 1);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    PeakScalars s;
+    HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) out4[k] = (double)s.bounds[k];
+    return SAC_OK;
+}
+
+extern "C" int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out)
+{
+    if (!h || !h->peak || !out) return fail(SAC_E_INVALID, "sac_get_peak_stats: not a SAC_KIND_PEAK handle");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int nc = h->cfg.n_chains;
+    std::vector<PeakScalars> sc((size_t)nc);
+    HIP_TRY(hipMemcpy(sc.data(), h->dPsc, (size_t)nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(peak_weights_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, h->stream,
+                       (const double *)h->dA, h->wi_stride, nc, h->cfg.n_peak, h->cfg.n_omega, h->dWeights);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> wts((size_t)nc * 4);
+    HIP_TRY(hipMemcpyAsync(wts.data(), h->dWeights, wts.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memset(out, 0, sizeof(*out));
+    const double steps = (double)h->last_steps, dn = (double)nc;
+    double cmin = sc[0].chi2_min;
+    for (int c = 0; c < nc; ++c) {
+        const PeakScalars &s = sc[(size_t)c];
+        if (h->last_stage == 2) out->sampled_chi2 += s.sum_chi2 / steps;
+        for (int k = 0; k < 11; ++k) {
+            out->accept_rates[k] += (h->last_stage == 2) ? s.acc[k] / steps : s.acc[k];
+            out->windows[k] += s.windows[k];
+        }
+        for (int k = 0; k < 4; ++k) { out->bounds[k] += (double)s.bounds[k]; out->weights[k] += wts[(size_t)c * 4 + k]; }
+        for (int k = 0; k < 6; ++k) (&out->edge_res[0][0])[k] += h->edge_rows[(size_t)c * 6 + k];
+        if (s.chi2_min < cmin) cmin = s.chi2_min;
+        out->proposals += s.counters[0];
+        out->evaluated += s.counters[1];
+        out->accepted += s.counters[2];
+        out->accepted_moves += s.counters[3];
+        out->columns_gathered += s.counters[4];
+        out->sweeps += s.sweep;
+    }
+    out->sampled_chi2 /= dn;
+    out->chi2_min = cmin;
+    for (int k = 0; k < 11; ++k) { out->accept_rates[k] /= dn; out->windows[k] /= dn; }
+    for (int k = 0; k < 4; ++k) { out->bounds[k] /= dn; out->weights[k] /= dn; }
+    for (int k = 0; k < 6; ++k) (&out->edge_res[0][0])[k] /= dn;
+    out->last_stage_ms = h->last_stage_ms;
+    out->last_kernel_ms = h->last_kernel_ms;
+    out->last_kernel_launches = h->last_launches;
+    return SAC_OK;
+}
+
+extern "C" int sac_get_histogram_peak(sac_handle_t *h, int32_t which, double *out)
+{
+    if (!h || !h->peak || !out) return fail(SAC_E_INVALID, "sac_get_histogram_peak: not a SAC_KIND_PEAK handle");
+    if (which < 0 || which > 3) return fail(SAC_E_INVALID, "sac_get_histogram_peak: which=%d", which);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t ng = (size_t)h->cfg.n_grid;
+    std::vector<double> tmp(ng);
+    std::fill(out, out + ng, 0.0);
+    for (int c = 0; c < h->hist_copies; ++c) {
+        HIP_TRY(hipMemcpy(tmp.data(), h->dHist + ((size_t)c * 4 + (size_t)which) * ng, ng * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ng; ++i) out[i] = (c == 0) ? tmp[i] : out[i] + tmp[i];
+    }
+    const double nc = (double)h->cfg.n_chains;
+    const double div = h->binned ? 1.0 : (double)h->last_steps;      // peak:1151-1154
+    for (size_t i = 0; i < ng; ++i) out[i] = out[i] / div / nc;
+    return SAC_OK;
+}
+
 extern "C" int sac_adjust_windows(sac_handle_t *h, int64_t steps, double theta)
 {
     int rc;
     if ((rc = stage_begin(h, "sac_adjust_windows", steps, theta))) return rc;
+    if (h->peak) return peak_adjust_windows(h, steps, theta);
     const int64_t per = steps / 10;                                  // free:873
     for (int round = 0; round < 10; ++round) {                       // free:869
         // free:871 zero the rates, free:873-880 `per` sweeps, free:883-895 retune.
@@ -670,6 +1288,7 @@ extern "C" int sac_sample(sac_handle_t *h, int64_t steps, double theta)
 {
     int rc;
     if ((rc = stage_begin(h, "sac_sample", steps, theta))) return rc;
+    if (h->peak) return peak_sample(h, steps, theta, false);
     HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * (size_t)h->cfg.n_grid * sizeof(double),
                            h->stream));                             // free:906
     if ((rc = run_sweeps(h, steps, theta, STAGE_SAMPLE, STAGE_ZERO_ACC, 0, 1.0))) return rc;
@@ -679,6 +1298,7 @@ extern "C" int sac_sample(sac_handle_t *h, int64_t steps, double theta)
 extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
 {
     if (!h || !out) return fail(SAC_E_INVALID, "sac_get_stats: null argument");
+    if (h->peak) return fail(SAC_E_INVALID, "sac_get_stats: use sac_get_peak_stats for SAC_KIND_PEAK");
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -719,6 +1339,7 @@ extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
 extern "C" int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6, double *accept_rates)
 {
     if (!h) return fail(SAC_E_INVALID, "sac_get_chain_stats: null handle");
+    if (h->peak) return peak_chain_stats(h, chain, out6, accept_rates);
     if (chain < 0 || chain >= h->cfg.n_chains)
         return fail(SAC_E_INVALID, "sac_get_chain_stats: chain %d outside 0..%d", chain, h->cfg.n_chains - 1);
     int rc;
@@ -742,6 +1363,7 @@ extern "C" int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6,
 extern "C" int sac_get_histogram(sac_handle_t *h, double *out)
 {
     if (!h || !out) return fail(SAC_E_INVALID, "sac_get_histogram: null argument");
+    if (h->peak) return fail(SAC_E_INVALID, "sac_get_histogram: use sac_get_histogram_peak for SAC_KIND_PEAK");
     if (h->last_stage != 2) return fail(SAC_E_STATE, "sac_get_histogram: no sample stage has run");
     int rc;
     if ((rc = use_device(h))) return rc;
@@ -761,6 +1383,7 @@ extern "C" int sac_get_histogram(sac_handle_t *h, double *out)
 extern "C" int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, double *steps_times_chains)
 {
     if (!h || !dst_device) return fail(SAC_E_INVALID, "sac_get_histogram_sum_device: null argument");
+    if (h->peak) return fail(SAC_E_INVALID, "sac_get_histogram_sum_device: not available for SAC_KIND_PEAK yet");
     if (h->last_stage != 2) return fail(SAC_E_STATE, "sac_get_histogram_sum_device: no sample stage has run");
     int rc;
     if ((rc = use_device(h))) return rc;

@@ -13,7 +13,11 @@ EXPORTS = [
     "sac_get_state", "sac_init_gbar", "sac_get_gbar", "sac_set_gbar", "sac_adjust_windows",
     "sac_sample", "sac_get_stats", "sac_get_chain_stats", "sac_get_histogram",
     "sac_get_histogram_sum_device", "sac_set_move_log", "sac_get_move_log",
+    "sac_upload_problem_peak", "sac_sample_bin", "sac_set_indiv_update", "sac_zero_accumulators",
+    "sac_get_peak_stats", "sac_get_histogram_peak", "sac_get_bounds",
 ]
+
+KIND_FREE, KIND_PEAK = 0, 1
 
 HIST_REFERENCE, HIST_ACCUMULATE = 0, 1
 
@@ -27,7 +31,8 @@ class Config(C.Structure):
                 ("n_omega", C.c_int32), ("n_chains", C.c_int32), ("n_grid", C.c_int64),
                 ("wi_0", C.c_int64), ("wi_m", C.c_int64), ("seed", C.c_uint64),
                 ("chain_offset", C.c_uint32), ("device", C.c_int32), ("hist_mode", C.c_int32),
-                ("hist_copies", C.c_int32), ("sweeps_per_launch", C.c_int32), ("reserved", C.c_int32)]
+                ("hist_copies", C.c_int32), ("sweeps_per_launch", C.c_int32), ("n_peak", C.c_int32),
+                ("fix_edge", C.c_int32), ("bosonic", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -36,6 +41,16 @@ class Stats(C.Structure):
                 ("proposals", C.c_uint64), ("evaluated", C.c_uint64), ("accepted", C.c_uint64),
                 ("accepted_moves", C.c_uint64), ("sweeps", C.c_uint64),
                 ("columns_gathered", C.c_uint64),
+                ("last_stage_ms", C.c_double), ("last_kernel_ms", C.c_double),
+                ("last_kernel_launches", C.c_int64)]
+
+
+class PeakStats(C.Structure):
+    _fields_ = [("sampled_chi2", C.c_double), ("chi2_min", C.c_double),
+                ("accept_rates", C.c_double * 11), ("windows", C.c_double * 11),
+                ("edge_res", (C.c_double * 2) * 3), ("bounds", C.c_double * 4), ("weights", C.c_double * 4),
+                ("proposals", C.c_uint64), ("evaluated", C.c_uint64), ("accepted", C.c_uint64),
+                ("accepted_moves", C.c_uint64), ("sweeps", C.c_uint64), ("columns_gathered", C.c_uint64),
                 ("last_stage_ms", C.c_double), ("last_kernel_ms", C.c_double),
                 ("last_kernel_launches", C.c_int64)]
 
@@ -70,6 +85,13 @@ def load_library():
     L.sac_get_histogram_sum_device.argtypes = [vp, vp, dp]
     L.sac_set_move_log.argtypes = [vp, C.c_int32, C.c_int64]
     L.sac_get_move_log.argtypes = [vp, vp, C.c_int64, ip]
+    L.sac_upload_problem_peak.argtypes = [vp, dp, dp, dp, dp]
+    L.sac_sample_bin.argtypes = [vp, C.c_int64, C.c_double]
+    L.sac_set_indiv_update.argtypes = [vp, C.c_int32]
+    L.sac_zero_accumulators.argtypes = [vp]
+    L.sac_get_peak_stats.argtypes = [vp, C.POINTER(PeakStats)]
+    L.sac_get_histogram_peak.argtypes = [vp, C.c_int32, dp]
+    L.sac_get_bounds.argtypes = [vp, C.c_int32, dp]
     for name in EXPORTS:
         if name != "sac_last_error":
             getattr(L, name).restype = C.c_int
@@ -90,15 +112,20 @@ class SacHandle:
 
     def __init__(self, n_tau, n_omega, n_grid, wi_0, wi_m, n_chains=1, par=1, symm=0, seed=0,
                  chain_offset=0, device=0, hist_mode=HIST_REFERENCE, hist_copies=0,
-                 sweeps_per_launch=0):
+                 sweeps_per_launch=0, kind=KIND_FREE, n_peak=0, fix_edge=0, bosonic=0):
         self.L = load_library()
-        self.cfg = Config(kind=0, par=par, symm=symm, n_tau=n_tau, n_omega=n_omega,
+        self.cfg = Config(kind=kind, par=par, symm=symm, n_tau=n_tau, n_omega=n_omega,
                           n_chains=n_chains, n_grid=n_grid, wi_0=wi_0, wi_m=wi_m, seed=seed,
                           chain_offset=chain_offset, device=device, hist_mode=hist_mode,
-                          hist_copies=hist_copies, sweeps_per_launch=sweeps_per_launch)
+                          hist_copies=hist_copies, sweeps_per_launch=sweeps_per_launch,
+                          n_peak=n_peak, fix_edge=fix_edge, bosonic=bosonic)
         self.h = C.c_void_p()
         self._check(self.L.sac_create(C.byref(self.cfg), C.byref(self.h)))
         self.n_tau, self.n_omega, self.n_grid, self.n_chains = n_tau, n_omega, n_grid, n_chains
+        self.kind = kind
+        self.n_state = 2 * (n_omega + n_peak) if kind == KIND_PEAK else n_omega
+        self.n_windows = 11 if kind == KIND_PEAK else 4
+        self.n_rates = 11 if kind == KIND_PEAK else 6
 
     def _check(self, rc):
         if rc != 0:
@@ -129,15 +156,15 @@ class SacHandle:
         wi = None if wi is None else np.ascontiguousarray(wi, dtype=np.int64)
         A = None if A is None else np.ascontiguousarray(A, dtype=np.float64)
         windows = None if windows is None else np.ascontiguousarray(windows, dtype=np.float64)
-        for a, n in ((wi, self.n_omega), (A, self.n_omega), (windows, 4)):
+        for a, n in ((wi, self.n_state), (A, self.n_state), (windows, self.n_windows)):
             if a is not None and a.shape != (n,):
                 raise SacError(f"state array has shape {a.shape}, expected ({n},)")
         self._check(self.L.sac_set_state(self.h, chain, _ip(wi), _dp(A), _dp(windows)))
 
     def get_state(self, chain=0):
-        wi = np.empty(self.n_omega, dtype=np.int64)
-        A = np.empty(self.n_omega)
-        w = np.empty(4)
+        wi = np.empty(self.n_state, dtype=np.int64)
+        A = np.empty(self.n_state)
+        w = np.empty(self.n_windows)
         self._check(self.L.sac_get_state(self.h, chain, _ip(wi), _dp(A), _dp(w)))
         return wi, A, w
 
@@ -167,9 +194,45 @@ class SacHandle:
 
     def chain_stats(self, chain=0):
         o = np.empty(6)
-        ar = np.empty(6)
+        ar = np.empty(self.n_rates)
         self._check(self.L.sac_get_chain_stats(self.h, chain, _dp(o), _dp(ar)))
-        return dict(sampled_chi2=o[0], chi2=o[1], chi2_min=o[2], sweeps=int(o[3]), accept_rates=ar)
+        return dict(sampled_chi2=o[0], chi2=o[1], chi2_min=o[2], sweeps=int(o[3]), accept_rates=ar,
+                    edge_mean=o[4:6].copy())
+
+    # ---- SAC_KIND_PEAK ----------------------------------------------------------------------
+    def upload_problem_peak(self, Kp, Kn, G, sigma_inv):
+        Kp = np.ascontiguousarray(Kp, dtype=np.float64)
+        Kn = None if Kn is None else np.ascontiguousarray(Kn, dtype=np.float64)
+        for K in (Kp, Kn):
+            if K is not None and K.shape != (self.n_grid, self.n_tau):
+                raise SacError(f"K has shape {K.shape}, expected {(self.n_grid, self.n_tau)}")
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        sigma_inv = np.ascontiguousarray(sigma_inv, dtype=np.float64)
+        self._check(self.L.sac_upload_problem_peak(self.h, _dp(Kp), _dp(Kn), _dp(G), _dp(sigma_inv)))
+
+    def sample_bin(self, steps, theta):
+        self._check(self.L.sac_sample_bin(self.h, int(steps), float(theta)))
+
+    def set_indiv_update(self, on):
+        self._check(self.L.sac_set_indiv_update(self.h, int(bool(on))))
+
+    def zero_accumulators(self):
+        self._check(self.L.sac_zero_accumulators(self.h))
+
+    def peak_stats(self):
+        s = PeakStats()
+        self._check(self.L.sac_get_peak_stats(self.h, C.byref(s)))
+        return s
+
+    def histogram_peak(self, which):
+        out = np.empty(self.n_grid)
+        self._check(self.L.sac_get_histogram_peak(self.h, int(which), _dp(out)))
+        return out
+
+    def bounds(self, chain=0):
+        b = np.empty(4)
+        self._check(self.L.sac_get_bounds(self.h, chain, _dp(b)))
+        return b
 
     def histogram(self):
         out = np.empty(self.n_grid)
