@@ -43,6 +43,7 @@ extern "C" {
 
 #define SAC_MAX_N_TAU   128
 #define SAC_MAX_N_OMEGA 2048
+#define SAC_MAX_PEAK_STATE 4224  /* peak: sampled deltas per chain, (1 or 2 axes) x (n_omega + n_peak) */
 
 typedef struct sac_handle sac_handle_t;
 
@@ -166,6 +167,13 @@ int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out);
 int sac_get_histogram_peak(sac_handle_t *h, int32_t which, double *out);
 /* ωi_pp, ωi_pc, ωi_np, ωi_nc of one chain (peak:14-17) */
 int sac_get_bounds(sac_handle_t *h, int32_t chain, double *out4);
+
+/* Population control for n_chains > 1 (no counterpart in the reference, which runs one chain):
+ * chain dst takes over the configuration of chain src (positions, amplitudes, Gbar, chi2, chi2_min,
+ * windows, rate accumulators, bounds) and continues on its OWN random stream and sweep counter. */
+int sac_copy_chain(sac_handle_t *h, int32_t src, int32_t dst);
+/* chi2 and chi2_min of every chain of the handle (n_chains doubles each; either may be NULL). */
+int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min);
 
 /* Debug/parity: record every proposal of one chain (up to capacity) during the following stages. */
 int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);

@@ -32,7 +32,7 @@ struct ChainScalars {
 
 struct MoveRec { double chi2_new; int flags; int move; };
 
-enum : int { STAGE_ZERO_ACC = 1, STAGE_SAMPLE = 2, STAGE_RETUNE = 4 };
+enum : int { STAGE_ZERO_ACC = 1, STAGE_SAMPLE = 2, STAGE_RETUNE = 4, STAGE_BOUNDS_AT_START = 8 };
 
 struct FreeParams {
     const double *K;            // [n_grid][ntp], tau contiguous, zero padded

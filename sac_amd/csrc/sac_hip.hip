@@ -227,7 +227,11 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) init_gbar_kernel(const F
 // from-scratch refresh of Gbar/chi2 (peak:1072-1073, 1120-1121), by flag the sampling work
 // (peak:1126-1147) and the window retune (peak:1079-1091).  XFER: the amplitudes change (weight
 // transfer between the axes), so they live in LDS and a block holds two chains.
-enum : int { STAGE_BOUNDS_AT_START = 8 };
+
+__host__ __device__ constexpr size_t peak_lds_bytes_per_wave(int wi_stride, bool xfer)
+{
+    return (size_t)wi_stride * (xfer ? 12u : 4u) + 26u * 8u;
+}
 
 template <int NTL, bool LOG, bool XFER>
 __global__ void __launch_bounds__(64 * (XFER ? 2 : WAVES_PER_BLOCK), XFER ? 2 : 4)
@@ -235,10 +239,14 @@ peak_stage_kernel(const PeakParams pp)
 {
     constexpr int WPB = XFER ? 2 : WAVES_PER_BLOCK;
     const FreeParams &p = pp.f;
-    __shared__ uint32_t s_wi[WPB][MAX_N_OMEGA];
-    __shared__ double s_A[XFER ? WPB : 1][XFER ? MAX_N_OMEGA : 1];
-    __shared__ double s_sc[WPB][26];   // windows[11], accept accumulators[11], sum chi2, edge sums[2]
+    // dynamic LDS, per wave: [amplitudes f64 x wi_stride (XFER)] [26 f64: windows[11], accept
+    // accumulators[11], sum chi2, edge sums[2]] [positions u32 x wi_stride]; sized by peak_lds_bytes()
+    extern __shared__ __align__(16) unsigned char s_dyn[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char *s_mine = s_dyn + (size_t)wave * peak_lds_bytes_per_wave(p.wi_stride, XFER);
+    double *s_A_w = reinterpret_cast<double *>(s_mine);
+    double *s_sc_w = s_A_w + (XFER ? p.wi_stride : 0);
+    uint32_t *s_wi_w = reinterpret_cast<uint32_t *>(s_sc_w + 26);
     const int chain = (int)blockIdx.x * WPB + wave;
     if (chain >= p.n_chains) return;
     const int lane = lane_id();
@@ -249,7 +257,7 @@ peak_stage_kernel(const PeakParams pp)
     Chain<NTL> c;
     c.Kb = Kp;
     c.col_bytes = (uint32_t)p.ntp * 8u;
-    c.wi = s_wi[wave];
+    c.wi = s_wi_w;
     c.lane = lane;
     c.n_omega = n;
     c.gmax = pp.wim;
@@ -260,8 +268,8 @@ peak_stage_kernel(const PeakParams pp)
     double *A_g = p.A + (size_t)chain * (size_t)p.wi_stride;
     double *A = A_g;
     if constexpr (XFER) {
-        for (int i = lane; i < n_used; i += 64) s_A[wave][i] = A_g[i];
-        A = s_A[wave];
+        for (int i = lane; i < n_used; i += 64) s_A_w[i] = A_g[i];
+        A = s_A_w;
     }
     c.A = A;
     c.A_uniform = 0.0;
@@ -282,7 +290,7 @@ peak_stage_kernel(const PeakParams pp)
     PeakScalars *scp = pp.psc + chain;
     c.chi2 = scp->chi2;
     c.chi2_min = scp->chi2_min;
-    double *win = s_sc[wave], *acc = s_sc[wave] + 11, *sum_chi2 = s_sc[wave] + 22, *edge = s_sc[wave] + 23;
+    double *win = s_sc_w, *acc = s_sc_w + 11, *sum_chi2 = s_sc_w + 22, *edge = s_sc_w + 23;
     const bool zero = (p.flags & STAGE_ZERO_ACC) != 0;
     if (lane < 11) { win[lane] = scp->windows[lane]; acc[lane] = zero ? 0.0 : scp->acc[lane]; }
     if (lane == 0) *sum_chi2 = zero ? 0.0 : scp->sum_chi2;
@@ -410,7 +418,7 @@ peak_stage_kernel(const PeakParams pp)
     }
     for (int i = lane; i < n_used; i += 64) wi_g[i] = c.wi[i];
     if constexpr (XFER) {
-        for (int i = lane; i < n_used; i += 64) A_g[i] = s_A[wave][i];
+        for (int i = lane; i < n_used; i += 64) A_g[i] = s_A_w[i];
     }
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
@@ -442,17 +450,15 @@ template <int NTL>
 __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const PeakParams pp)
 {
     const FreeParams &p = pp.f;
-    __shared__ uint32_t s_wi[WAVES_PER_BLOCK][MAX_N_OMEGA];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int chain = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (chain >= p.n_chains) return;
     const int lane = lane_id();
     const int n_p = pp.n_p, n = pp.n_cont;
-    const int n_used = pp.sample_neg ? 2 * (n_p + n) : (n_p + n);
     Chain<NTL> c;
     c.Kb = reinterpret_cast<const char *>(p.K);
     c.col_bytes = (uint32_t)p.ntp * 8u;
-    c.wi = s_wi[wave];
+    c.wi = p.wi + (size_t)chain * (size_t)p.wi_stride;   // read in place (one pass)
     c.lane = lane;
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
@@ -461,8 +467,6 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const P
         c.G[t] = p.G[j];
         c.sinv[t] = p.sinv[j];
     }
-    const uint32_t *wi_g = p.wi + (size_t)chain * (size_t)p.wi_stride;
-    for (int i = lane; i < n_used; i += 64) c.wi[i] = wi_g[i];
     const double *A = p.A + (size_t)chain * (size_t)p.wi_stride;
     peak_refresh_gbar<NTL>(c, c.Kb, reinterpret_cast<const char *>(pp.Kn), A, n_p, n, pp.sample_neg);
     double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
@@ -578,8 +582,8 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
     if (peak) {
         if (cfg->n_peak < 1) return fail(SAC_E_INVALID, "sac_create: n_peak=%d", cfg->n_peak);
         const long long used = (sample_neg ? 2ll : 1ll) * ((long long)cfg->n_omega + cfg->n_peak);
-        if (used > SAC_MAX_N_OMEGA)
-            return fail(SAC_E_INVALID, "sac_create: %lld sampled deltas per chain exceed %d", used, SAC_MAX_N_OMEGA);
+        if (used > SAC_MAX_PEAK_STATE)
+            return fail(SAC_E_INVALID, "sac_create: %lld sampled deltas per chain exceed %d", used, SAC_MAX_PEAK_STATE);
         if (cfg->wi_0 < 0 || cfg->n_grid != cfg->wi_m + 1)
             return fail(SAC_E_INVALID, "sac_create: peak needs wi_0 >= 0 and n_grid == wi_m + 1");
     }
@@ -1077,8 +1081,14 @@ static int run_peak_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int fl
         const int wpb = xfer ? 2 : WAVES_PER_BLOCK;
         const dim3 grid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), block(64 * wpb);
         const int variant = (xfer ? 4 : 0) | (h->cfg.n_tau <= 64 ? 0 : 2) | (log ? 1 : 0);
-#define SAC_PLAUNCH(NTL_, LOG_, X_) \
-    hipLaunchKernelGGL((peak_stage_kernel<NTL_, LOG_, X_>), grid, block, 0, h->stream, pp)
+        const size_t lds = (size_t)wpb * peak_lds_bytes_per_wave(h->wi_stride, xfer);
+#define SAC_PLAUNCH(NTL_, LOG_, X_)                                                                      \
+    do {                                                                                                 \
+        if (lds > 48 * 1024)                                                                             \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&peak_stage_kernel<NTL_, LOG_, X_>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL((peak_stage_kernel<NTL_, LOG_, X_>), grid, block, lds, h->stream, pp);        \
+    } while (0)
         switch (variant) {
         case 0: SAC_PLAUNCH(1, false, false); break;
         case 1: SAC_PLAUNCH(1, true, false); break;
@@ -1357,6 +1367,74 @@ extern "C" int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6,
     }
     if (accept_rates)
         for (int k = 0; k < 6; ++k) accept_rates[k] = (h->last_stage == 2) ? s.acc[k] / steps : s.acc[k];
+    return SAC_OK;
+}
+
+extern "C" int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min)
+{
+    if (!h) return fail(SAC_E_INVALID, "sac_get_chain_chi2: null handle");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t nc = (size_t)h->cfg.n_chains;
+    if (h->peak) {
+        std::vector<PeakScalars> v(nc);
+        HIP_TRY(hipMemcpy(v.data(), h->dPsc, nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < nc; ++c) {
+            if (chi2) chi2[c] = v[c].chi2;
+            if (chi2_min) chi2_min[c] = v[c].chi2_min;
+        }
+    } else {
+        std::vector<ChainScalars> v(nc);
+        HIP_TRY(hipMemcpy(v.data(), h->dSc, nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < nc; ++c) {
+            if (chi2) chi2[c] = v[c].chi2;
+            if (chi2_min) chi2_min[c] = v[c].chi2_min;
+        }
+    }
+    return SAC_OK;
+}
+
+extern "C" int sac_copy_chain(sac_handle_t *h, int32_t src, int32_t dst)
+{
+    if (!h) return fail(SAC_E_INVALID, "sac_copy_chain: null handle");
+    const int nc = h->cfg.n_chains;
+    if (src < 0 || src >= nc || dst < 0 || dst >= nc)
+        return fail(SAC_E_INVALID, "sac_copy_chain: chains %d -> %d outside 0..%d", src, dst, nc - 1);
+    if (!h->state_set || !h->gbar_set) return fail(SAC_E_STATE, "sac_copy_chain: state / Gbar not set");
+    if (src == dst) return SAC_OK;
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t ws = (size_t)h->wi_stride;
+    HIP_TRY(hipMemcpy(h->dWi + dst * ws, h->dWi + src * ws, ws * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(h->dA + dst * ws, h->dA + src * ws, ws * sizeof(double), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(h->dGbar + (size_t)dst * SAC_MAX_N_TAU, h->dGbar + (size_t)src * SAC_MAX_N_TAU,
+                      SAC_MAX_N_TAU * sizeof(double), hipMemcpyDeviceToDevice));
+    // scalars: everything but the destination's own sweep counter (its Philox stream) and counters
+    if (h->peak) {
+        PeakScalars a, b;
+        HIP_TRY(hipMemcpy(&a, h->dPsc + src, sizeof(a), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&b, h->dPsc + dst, sizeof(b), hipMemcpyDeviceToHost));
+        const unsigned long long sweep = b.sweep;
+        unsigned long long cnt[5];
+        std::memcpy(cnt, b.counters, sizeof(cnt));
+        b = a;
+        b.sweep = sweep;
+        std::memcpy(b.counters, cnt, sizeof(cnt));
+        HIP_TRY(hipMemcpy(h->dPsc + dst, &b, sizeof(b), hipMemcpyHostToDevice));
+    } else {
+        ChainScalars a, b;
+        HIP_TRY(hipMemcpy(&a, h->dSc + src, sizeof(a), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&b, h->dSc + dst, sizeof(b), hipMemcpyDeviceToHost));
+        const unsigned long long sweep = b.sweep;
+        unsigned long long cnt[5];
+        std::memcpy(cnt, b.counters, sizeof(cnt));
+        b = a;
+        b.sweep = sweep;
+        std::memcpy(b.counters, cnt, sizeof(cnt));
+        HIP_TRY(hipMemcpy(h->dSc + dst, &b, sizeof(b), hipMemcpyHostToDevice));
+    }
     return SAC_OK;
 }
 

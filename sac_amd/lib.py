@@ -14,7 +14,7 @@ EXPORTS = [
     "sac_sample", "sac_get_stats", "sac_get_chain_stats", "sac_get_histogram",
     "sac_get_histogram_sum_device", "sac_set_move_log", "sac_get_move_log",
     "sac_upload_problem_peak", "sac_sample_bin", "sac_set_indiv_update", "sac_zero_accumulators",
-    "sac_get_peak_stats", "sac_get_histogram_peak", "sac_get_bounds",
+    "sac_get_peak_stats", "sac_get_histogram_peak", "sac_get_bounds", "sac_copy_chain", "sac_get_chain_chi2",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -228,6 +228,14 @@ class SacHandle:
         out = np.empty(self.n_grid)
         self._check(self.L.sac_get_histogram_peak(self.h, int(which), _dp(out)))
         return out
+
+    def chain_chi2(self):
+        a, b = np.empty(self.cfg.n_chains), np.empty(self.cfg.n_chains)
+        self._check(self.L.sac_get_chain_chi2(self.h, _dp(a), _dp(b)))
+        return a, b
+
+    def copy_chain(self, src, dst):
+        self._check(self.L.sac_copy_chain(self.h, int(src), int(dst)))
 
     def bounds(self, chain=0):
         b = np.empty(4)

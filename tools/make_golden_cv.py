@@ -36,4 +36,22 @@ def main():
     os.system(f"chmod -R u+w {OUT}")
 
 if __name__ == "__main__":
-    sys.exit(main())
+    main()
+    peak_fixture()
+
+
+def peak_fixture():
+    """Committed reference run of sac_peak.jl (statistical oracle for the peak path):
+    sac/peak/out_files/fermionic2/Np_01/A0_0.700/{t.in,in_peak.in,anneal.csv,sample.csv,accept_rate.csv}
+    -> tests/golden/peak_f2/ (data only; the other committed peak runs were written by older versions of
+    sac_peak.jl whose accept_rate.csv header and fixed +/- weight split differ from the current code)."""
+    src = "/root/reference/sac/peak/out_files/fermionic2/Np_01/A0_0.700"
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "peak_f2")
+    os.makedirs(out, exist_ok=True)
+    for name in ("t.in", "in_peak.in", "anneal.csv", "sample.csv", "accept_rate.csv"):
+        shutil.copyfile(f"{src}/{name}", f"{out}/{name}")
+    os.system(f"chmod -R u+w {out}")
+    with open(f"{out}/in_peak.in") as f:          # keep the six parameter rows, drop the commentary
+        rows = f.readlines()[:6]
+    with open(f"{out}/in_peak.in", "w") as f:
+        f.writelines(rows)
