@@ -1,0 +1,97 @@
+"""Cross-validation wrapper: mirror of sac/cross_validation/cross_val.jl (free_cv cv:6-144,
+peak_cv cv:147-312) above the C ABI.  For replica `rep`, half `ab` it runs the sampler's main anneal
+with tol = 1e-6 and appends [Theta, cov * Gbar] to GSAC.csv after every Theta stage (cv:105-108);
+calc_cv.jl then scores half a's Gbar against half b's data.  With n_chains > 1 the row holds the
+chain-averaged Gbar."""
+import os
+import shutil
+
+import numpy as np
+
+from .free import FreeSAC, _jl_round, jl_float
+from .peak import PeakSAC
+
+
+def _append_gsac(path, theta, cov, gbar):
+    row = [_jl_round(theta, 8)] + list(cov @ gbar)                  # cv:106
+    with open(path, "a") as f:
+        f.write(",".join(jl_float(float(v)) for v in row) + "\n")
+
+
+def free_cv(rep, ab, in_file="in_free.in", **kw):
+    """cv:6-144.  Returns the FreeSAC object (its output_folder holds GSAC.csv, anneal.csv, ...)."""
+    s = FreeSAC.from_infile(in_file, **kw)
+    G_folder = s.G_file                                             # row 5 holds the folder here (cv:14)
+    s.G_file = "%s/t_%03i%s.in" % (G_folder, rep, ab)               # cv:17
+    base = s.output_folder[:-5] if (s.symm == 1 and s.kernel_type != "bosonic") else s.output_folder
+    s.output_folder = base + "/%03i%s/free" % (rep, ab)             # cv:18
+    if s.symm == 1 and s.kernel_type != "bosonic":
+        s.output_folder += "_symm"                                  # cv:24-26
+    return _free_cv_run(s, in_file)
+
+
+def _free_cv_run(s, in_file=None):
+    os.makedirs(s.output_folder, exist_ok=True)
+    if s.is_root:
+        if in_file and os.path.exists(in_file):
+            shutil.copyfile(in_file, s.output_folder + "/in_free.in")   # cv:32-33
+        if s.timedata is None:
+            shutil.copyfile(s.G_file, s.output_folder + "/t.in")
+    s.tol = 1e-6                                                    # cv:50
+    gsac = s.output_folder + "/GSAC.csv"
+    if s.is_root:
+        open(gsac, "w").close()                                     # cv:54-58
+    s.init_outfiles()
+    s.write_log("Beginning Initialization.", "w")
+    s.initialize()                                                  # cv:67-75
+    s.write_log("Initialization Finished.")
+    s.write_log("Beginning Equillibration.")
+    s.fast_anneal()                                                 # cv:85
+    s.write_log("Equillibration Finished.")
+    s.write_log("Beginning Main Anneal.")
+
+    def dump(i, theta):
+        g = s.mean_gbar()
+        if s.is_root:
+            _append_gsac(gsac, theta, s.td.cov, g)
+
+    s.main_anneal(on_stage=dump)                                    # cv:98-140
+    s.write_log("Main Anneal Finished.")
+    return s
+
+
+def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, **kw):
+    """cv:147-312: as free_cv for the peak parameterisation (initial sampling, then the anneal with the
+    GSAC dump)."""
+    s = PeakSAC.from_infile(in_file, A_0_in=A_0, N_p_in=N_p, **kw)
+    G_folder = s.G_file
+    s.G_file = "%s/t_%03i%s.in" % (G_folder, rep, ab)
+    tail = "/Np_%02i/A0_%.3f" % (s.N_p, s.A_0)                     # cv:158-177
+    root = s.output_folder[: -len(tail)]
+    symm_tag = "_symm" if (s.symm == 1 and s.kernel_type != "bosonic") else ""
+    if symm_tag:
+        root = root[: -len(symm_tag)]
+    s.output_folder = root + "/%03i%s/peak" % (rep, ab) + symm_tag + tail
+    os.makedirs(s.output_folder, exist_ok=True)
+    s.tol = 1e-6
+    gsac = s.output_folder + "/GSAC.csv"
+    open(gsac, "w").close()
+    s.init_outfiles()
+    s.write_log("Beginning Initialization.", "w")
+    s.initialize()
+    s.write_log("Initialization Finished.")
+    s.intial_sampling(s.theta_0)
+    if s.chi2_min > 1000 * s.td.n_tau:
+        s.indiv_update = True
+        s.initialize()
+        s.intial_sampling(s.theta_0)
+    s.repair_chains()
+
+    def dump(i, theta):
+        g = np.zeros(s.td.n_tau)
+        for c in range(s.n_chains):
+            g += s.h.get_gbar(c)[0][: s.td.n_tau]
+        _append_gsac(gsac, theta, s.td.cov, g / s.n_chains)
+
+    s.run_anneal(s.theta_0, on_stage=dump)
+    return s

@@ -45,6 +45,12 @@ class Comm:
                                accept_rates=[float(x) / n for x in buf[1:7]],
                                windows=[float(x) / n for x in buf[7:11]], n_chains=int(n))
 
+    def sum_vector(self, v):
+        """All-reduce(sum) of a small host vector (e.g. the chain-summed Gbar of the cross-validation dump)."""
+        t = torch.as_tensor(v, dtype=torch.float64).to(self.device)
+        dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
     def merge_stats(self, st, n_chains=None):
         """st: sac_stats_t-like (sampled_chi2, chi2_min, accept_rates[6], windows[4])."""
         n = n_chains if n_chains is not None else getattr(st, "n_chains", 1)

@@ -259,13 +259,25 @@ class FreeSAC:
             self.adjust_windows(self.anneal_steps // 2, theta)
             self.sample(self.anneal_steps // 2, theta)
 
-    def main_anneal(self, wr=False):                                # free:1051-1094
+    def mean_gbar(self):
+        """Gbar (eigenbasis) averaged over this handle's chains (one chain: the reference's self.Gbar)."""
+        g = np.zeros(self.td.n_tau)
+        for c in range(self.n_chains):
+            g += self.h.get_gbar(c)[0][: self.td.n_tau]
+        if self.comm is not None:
+            tot = self.comm.sum_vector(np.concatenate([g, [float(self.n_chains)]]))
+            return tot[:-1] / tot[-1]
+        return g / self.n_chains
+
+    def main_anneal(self, wr=False, on_stage=None):                 # free:1051-1094
         theta = self.theta_0
         n_tau = self.td.n_tau
         for i in range(1, self.N_anneal + 1):
             steps = self.anneal_steps
             self.adjust_windows(steps, theta)
             self.sample(steps, theta)
+            if on_stage is not None:                                # cross_val.jl:105-108 hooks in here
+                on_stage(i, theta)
             if self.is_root:
                 with open(self.anneal_file, "a") as f:              # free:1064-1068
                     vals = [float(i), _jl_round(theta, 8), _jl_round(self.chi2_min / n_tau, 4),

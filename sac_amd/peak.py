@@ -271,13 +271,15 @@ class PeakSAC:
         self.adjust_windows(self.anneal_steps, 2 * theta_0)
         self._merge()
 
-    def run_anneal(self, theta_0, wr=False):                        # peak:1289-1350
+    def run_anneal(self, theta_0, wr=False, on_stage=None):         # peak:1289-1350
         from .free import _jl_round, jl_float
         theta, n_tau = theta_0, self.td.n_tau
         for i in range(1, self.N_anneal + 1):
             steps = self.anneal_steps
             self.adjust_windows(steps, theta)
             self.sample(steps, theta)
+            if on_stage is not None:
+                on_stage(i, theta)
             edge_p, edge_n, A0_p, A0_n, Ac_p, Ac_n = self._edges_and_weights()
             vals = [theta, self.chi2_min / n_tau, self.sampled_chi2 / n_tau, edge_p, edge_n, A0_p, A0_n, Ac_p, Ac_n]
             with open(self.anneal_file, "a") as f:                  # peak:1315-1319
