@@ -113,6 +113,40 @@ void ora_peak_zero_spec(ora_peak_t *s);
 void ora_peak_get_spec(const ora_peak_t *s, int which, double *out);
 void ora_peak_get_counters(const ora_peak_t *s, uint64_t out[5]);
 
+/* ---- edge parameterisation (sac/edge/sac_edge.jl), see sac_oracle_edge.c ---------------------- */
+typedef struct {
+    int32_t n_tau, n_e, n_omega;   /* N_tau, N_e, N_w = N_e + N_c */
+    int32_t n_rl;                  /* 1: single_edge / double_edge_symm, 2: double_edge_in / _out */
+    int32_t double_in, fix_edge;
+    int64_t wi0, n_grid;           /* wi_0 and N_wi of the kernel tables */
+    double A_c, A_r, d0, w_floor[2], w_m, dw, c[2];
+} ora_edge_cfg_t;
+typedef struct ora_edge ora_edge_t;
+double ora_sac_log(double x);
+double ora_sac_exp(double x);
+/* K, dK, d2K: n_rl borrowed tables each, [n_grid][n_tau] */
+ora_edge_t *ora_edge_create(const ora_edge_cfg_t *cfg, const double *const *K, const double *const *dK,
+                            const double *const *d2K, const double *G, const double *sigma_inv);
+void ora_edge_destroy(ora_edge_t *s);
+void ora_edge_set_state(ora_edge_t *s, const double *w, const double *A, const double *dw, const int64_t *nm,
+                        const double *scal);
+void ora_edge_get_state(const ora_edge_t *s, double *w, double *A, double *dw, int64_t *nm, double *scal);
+void ora_edge_init_gbar(ora_edge_t *s);
+void ora_edge_profile(ora_edge_t *s, int rl, double n0, double eps0, double *out);
+void ora_edge_get_gbar(const ora_edge_t *s, double *gbar, double *chi2, double *chi2_min);
+void ora_edge_use_philox(ora_edge_t *s, uint64_t seed, uint32_t chain, uint64_t sweep0);
+void ora_edge_set_log(ora_edge_t *s, ora_move_rec_t *log, int64_t cap);
+int64_t ora_edge_log_len(const ora_edge_t *s);
+uint64_t ora_edge_sweep_counter(const ora_edge_t *s);
+int64_t ora_edge_violations(const ora_edge_t *s);
+void ora_edge_get_counters(const ora_edge_t *s, uint64_t out[5]);
+void ora_edge_run_updates(ora_edge_t *s, int64_t steps, double theta);              /* edge:1260 */
+void ora_edge_run_bins(ora_edge_t *s, int64_t steps, int64_t bins, double theta);   /* edge:1357 */
+void ora_edge_get_results(const ora_edge_t *s, double *res21, double *amp_ar6);
+void ora_edge_get_accept_rates(const ora_edge_t *s, int m, int rl, double *out);
+void ora_edge_get_spec(const ora_edge_t *s, int which, int rl, double *out);
+void ora_edge_get_avg(const ora_edge_t *s, double *w_avg, double *A_avg);
+
 #ifdef __cplusplus
 }
 #endif
