@@ -1,7 +1,7 @@
 # Builds libsac_hip.so (the product) for gfx950 and the CPU oracle (test infrastructure).
 HIPCC ?= /opt/rocm/bin/hipcc
 HIPFLAGS ?= -O3 -std=c++20 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -Wall -Wno-unused-value
-SRC = sac_amd/csrc/sac_hip.hip
+SRC = sac_amd/csrc/sac_hip.hip sac_amd/csrc/sac_edge.hip
 HDR = $(wildcard sac_amd/csrc/*.h) include/sac_hip.h
 
 all: sac_amd/libsac_hip.so oracle
@@ -10,7 +10,7 @@ sac_amd/libsac_hip.so: $(SRC) $(HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
 
 asm: $(SRC) $(HDR)
-	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/sac_hip.s $(SRC) -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/sac_hip.s sac_amd/csrc/sac_hip.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt
 
 oracle:
 	$(MAKE) -s -C oracle

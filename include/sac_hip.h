@@ -179,6 +179,72 @@ int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min);
 int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);
 int sac_get_move_log(sac_handle_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
 
+/* ===========================================================================================
+ * edge parameterisation (sac/edge/sac_edge.jl, "edge:NNN"): its own handle type.  The boundary is
+ * run_bins(self, steps, bins, theta) (edge:1357), the one stage function the annealing routines call
+ * (edge:1660, 1741, 1814, 2052), plus calc_Gbar!(self, 1) / calc_chi2 at (re)initialisation
+ * (edge:559-561, 1728-1730).  State arrays have the reference's shape [N_w+1, 2] (column-major:
+ * rightward side, then leftward side; row 1 is the reference's unused leading slot).
+ * =========================================================================================== */
+#define SAC_MAX_N_EDGE 256      /* N_e; N_w = N_e + N_c <= 2 * SAC_MAX_N_EDGE */
+
+typedef struct sac_edge sac_edge_t;
+
+typedef struct {
+    int32_t  n_tau, n_e, n_omega;   /* N_tau, N_e, N_w (edge:7-8, 43) */
+    int32_t  n_rl;                  /* 1: single_edge, double_edge_symm; 2: double_edge_in / _out (edge:111) */
+    int32_t  double_in;             /* mode == :double_edge_in (edge:800, 907) */
+    int32_t  fix_edge;              /* edge:115 */
+    int32_t  n_chains, device;
+    int64_t  wi_0, n_grid;          /* wi_0 and N_wi of the kernel tables (edge:169-172) */
+    double   A_c, A_r, d0;          /* edge:9-11 */
+    double   w_floor[2], w_m, d_omega;   /* edge:13-14, 20 */
+    double   c[2];                  /* edge:23 */
+    uint64_t seed;
+    uint32_t chain_offset;
+    int32_t  sweeps_per_launch;     /* 0 = default */
+    int32_t  hist_copies;           /* 0 = 1; n_chains = one private histogram per chain (bit-reproducible) */
+    int32_t  reserved;
+} sac_edge_config_t;
+
+typedef struct {
+    double   chi2_res[3];           /* after bin_averages (edge:1436-1449): [1] mean, [2] sigma of the bin means */
+    double   edge_res[3][2], n0_res[3][2], wn0_res[3][2];
+    double   amp_accept_rates[3][2];/* amplitude_accept_rates (edge:69) */
+    double   n0[2], eps0[2], dn0[2], deps0[2];
+    double   chi2, chi2_min;
+    uint64_t sweeps, proposals, evaluated, accepted, lookups, violations;
+    double   last_stage_ms;
+} sac_edge_results_t;
+
+int sac_edge_create(const sac_edge_config_t *cfg, sac_edge_t **out);
+int sac_edge_destroy(sac_edge_t *h);
+/* K_array, dK_array, d2K_array of init_kernal! (edge:167-242): per side a [N_tau, N_wi] column-major slice */
+int sac_edge_upload_problem(sac_edge_t *h, const double *const *K, const double *const *dK,
+                            const double *const *d2K, const double *G, const double *sigma_inv);
+/* omega_array, A_array, D_omega_array, n_multi (edge:51-53, 72-73); scal8 = n0[2], eps_0[2], Dn0[2], Deps_0[2]
+ * (edge:24-27).  chain = -1: all chains.  Any pointer may be NULL (left unchanged).  Also what
+ * anneal_and_sample's save/restore needs (edge:1671-1675, 1724-1726). */
+int sac_edge_set_state(sac_edge_t *h, int32_t chain, const double *w, const double *A, const double *dw,
+                       const int64_t *n_multi, const double *scal8);
+int sac_edge_get_state(sac_edge_t *h, int32_t chain, double *w, double *A, double *dw, int64_t *n_multi,
+                       double *scal8);
+/* calc_Gbar!(self, 1); chi2 = calc_chi2(self); chi2_min = chi2 */
+int sac_edge_init_gbar(sac_edge_t *h);
+/* run_bins(self, steps, bins, theta)  edge:1357-1379 */
+int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, double theta);
+/* chain = -1: mean over chains (chi2_min: minimum; counters: sums) */
+int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_results_t *out);
+/* accept_rates[m, :, side] after the last adjust_D (edge:1386-1387): N_w+1 doubles */
+int sac_edge_get_accept_rates(sac_edge_t *h, int32_t chain, int32_t m, int32_t side, double *out);
+/* sampled_spec[:, which, side] (edge:75, 1322-1331): accumulated sums, N_wi doubles, chain mean */
+int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side, double *out);
+/* omega_avg, A_avg (edge:83-84, 1314-1315): [N_w+1, 2] accumulated sums */
+int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, double *A_avg);
+int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min);
+int sac_edge_set_move_log(sac_edge_t *h, int32_t chain, int64_t capacity);
+int sac_edge_get_move_log(sac_edge_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
+
 #ifdef __cplusplus
 }
 #endif

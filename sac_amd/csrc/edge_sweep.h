@@ -1,0 +1,581 @@
+// Device side of the `edge` parameterisation (gfx950 only): one wavefront = one Markov chain of
+// sac/edge/sac_edge.jl ("edge:NNN" = line NNN of that file), lane = tau index.
+//
+// The chain's small arrays (positions, amplitudes, windows, cluster sizes, accept counters) live in
+// LDS; Gbar, G, sigma^-1 in registers; K_curr / K_new (one column per delta, edge:59-60) in global
+// memory, where lane t only ever touches element t of a column.  Control flow depends only on
+// wave-uniform values (LDS reads of the same address, Philox blocks computed redundantly by every
+// lane), so the wave never diverges.  Arithmetic order is the one fixed in DESIGN.md "edge" and
+// implemented independently by the CPU oracle.
+#pragma once
+#include "free_sweep.h"
+#include "wave_ops.h"
+
+namespace sacdev {
+
+enum : int { EDGE_BIN_START = 1, EDGE_BIN_END = 2 };
+enum : int { ED_SINGLE = 41, ED_MULTI = 43, ED_MULTI_RETRY = 45, ED_AMP = 47, ED_CONT = 49, ED_CONT_AMP = 50,
+             ED_CONT_AMP_RETRY = 51 };
+
+struct EdgeScalars {
+    double chi2, chi2_min;
+    double n0[2], eps0[2], dn0[2], deps0[2];
+    double amp_ar[3][2];                 // amplitude_accept_rates (edge:69)
+    double chi2_res[3], edge_res[3][2], n0_res[3][2], wn0_res[3][2];   // edge:78-81
+    unsigned long long sweep;
+    unsigned long long counters[5];      // proposals, evaluated, accepted, -, Taylor lookups
+    unsigned long long violations;       // check_w failures (edge:658-718)
+};
+
+struct EdgeParams {
+    const double *tab[2];       // per side: [n_grid][3][ntp]  (K, dK, d2K interleaved per column)
+    const double *G, *sinv;     // [128] zero padded
+    double *w, *A, *dw, *mw;    // [n_chains][2][S], Julia index k = 1..N+1 kept (slot 0 unused)
+    int *nm;                    // [n_chains][2][S]
+    double *arc;                // [n_chains][2 side][2 move][S] accept_rates
+    double *kcurr, *knew;       // [n_chains][2][S][ntp]
+    double *gbar;               // [n_chains][128]
+    double *wavg, *aavg;        // [n_chains][2][S]
+    double *hist;               // [hist_copies][2 side][2 which][n_grid]
+    EdgeScalars *sc;
+    MoveRec *log;
+    unsigned long long *log_len;
+    long long log_cap;
+    int log_chain;
+    int n_chains, n_tau, ntp, NE, N, S, n_rl, double_in, fix_edge, hist_copies, hist_exclusive;
+    long long n_grid, wi0;
+    double A_c, A_r, d0, w_floor[2], w_m, dwg, c[2];
+    uint32_t seed_lo, seed_hi, chain_offset;
+    int n_sweeps, flags;
+    double steps_in_bin, inv2theta;
+};
+
+// exp(x), |x| < 700: fdlibm e_exp.c scheme, IEEE operations in this fixed order (oracle: sac_exp)
+__device__ __forceinline__ double sac_exp(double x)
+{
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                 P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    double hi = x, lo = 0.0;
+    int k = 0;
+    if (__builtin_fabs(x) > 0.34657359027997264) {
+        k = (int)(invln2 * x + ((x < 0.0) ? -0.5 : 0.5));
+        const double t = (double)k;
+        hi = x - t * ln2HI;
+        lo = t * ln2LO;
+    }
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((r * c) / (c - 2.0) - r);
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    uint64_t b = __builtin_bit_cast(uint64_t, y);
+    b += (uint64_t)((int64_t)k << 52);
+    return __builtin_bit_cast(double, b);
+}
+
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_xor(v, m, 64); v = (o < v) ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const double o = __shfl_xor(v, m, 64); v = (o > v) ? o : v; }
+    return v;
+}
+
+template <int NTL>
+struct EdgeChain {
+    const EdgeParams *p;
+    int lane, chain;
+    uint32_t chain_id, sweep_lo, sweep_hi;
+    // LDS (per side arrays of S entries)
+    double *w[2], *A[2], *dwn[2], *mw[2], *arc[2][2], *tmpd, *tmpd2, *tempA;
+    int *nm[2], *bins;
+    // global, this chain
+    double *kcurr[2], *knew[2];
+    uint32_t off[NTL];          // byte offset of this lane's tau element(s) inside a column
+    double gbar[NTL], G[NTL], sinv[NTL];
+    double chi2, chi2_min;
+    double n0[2], eps0[2], dn0[2], deps0[2], amp_ar[3][2];
+    double wb0[2], wbf[2];
+    double inv2theta;
+    unsigned long long n_prop, n_eval, n_acc, n_cols;
+    MoveRec *log;
+    long long log_cap;
+    unsigned long long log_pos;
+
+    __device__ __forceinline__ u32x4 block(uint32_t move, uint32_t iter, uint32_t b) const
+    {
+        return philox4x32_10(iter, sweep_lo, sweep_hi | (move << 16) | (b << 24), chain_id, p->seed_lo, p->seed_hi);
+    }
+
+    template <bool LOG>
+    __device__ __forceinline__ void rec(int move, bool evaluated, bool accepted, double chi2_new)
+    {
+        n_prop += 1;
+        n_eval += evaluated ? 1 : 0;
+        n_acc += accepted ? 1 : 0;
+        if constexpr (LOG) {
+            if (log != nullptr) {
+                if ((long long)log_pos < log_cap && lane == 0) {
+                    MoveRec r;
+                    r.chi2_new = evaluated ? chi2_new : 0.0;
+                    r.flags = (evaluated ? 1 : 0) | (accepted ? 2 : 0);
+                    r.move = move;
+                    log[log_pos] = r;
+                }
+                log_pos += 1;
+            }
+        }
+    }
+
+    __device__ __forceinline__ double chi2_of(const double (&g)[NTL]) const
+    {
+        double term = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const double d = (g[t] - G[t]) * sinv[t];
+            term = (t == 0) ? d * d : term + d * d;
+        }
+        return wave_sum_uniform(term);
+    }
+
+    // K(w) by the reference's lookup (edge:626-633): this lane's tau element(s)
+    __device__ __forceinline__ void taylor(int rl, double wk, double (&out)[NTL])
+    {
+        const long long wi = (long long)__builtin_floor(wk / p->dwg);
+        const double d = wk - ((double)wi * p->dwg);
+        const double d2 = d * d;
+        long long col = wi - p->wi0;
+        col = col < 0 ? 0 : (col >= p->n_grid ? p->n_grid - 1 : col);
+        const char *b = reinterpret_cast<const char *>(p->tab[rl]) + (size_t)col * 3u * (size_t)p->ntp * 8u;
+        const size_t cb = (size_t)p->ntp * 8u;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const double k0 = *reinterpret_cast<const double *>(b + off[t]);
+            const double k1 = *reinterpret_cast<const double *>(b + cb + off[t]);
+            const double k2 = *reinterpret_cast<const double *>(b + 2 * cb + off[t]);
+            out[t] = (k0 + (k1 * d)) + (k2 * d2);
+        }
+        n_cols += 1;
+    }
+
+    __device__ __forceinline__ double col_get(const double *base, int k, int t) const
+    {
+        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t)k * p->ntp * 8u + off[t]);
+    }
+    __device__ __forceinline__ void col_put(double *base, int k, int t, double v) const
+    {
+        *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (size_t)k * p->ntp * 8u + off[t]) = v;
+    }
+
+    // ln U < (chi2 - chi2_new)/(2 theta)  <=>  rand() < P  (edge:863-864)
+    __device__ __forceinline__ bool accept_lt(double chi2_new, double u) const
+    {
+        return log_u01(u) < (chi2 - chi2_new) * inv2theta;
+    }
+
+    __device__ __forceinline__ void commit_chi2(double chi2_new)
+    {
+        chi2 = chi2_new;
+        if (chi2_new < chi2_min) chi2_min = chi2_new;
+    }
+
+    __device__ __forceinline__ double arr_max(const double *a, int lo, int hi) const
+    {
+        double m = a[lo];
+        for (int i = lo + lane; i <= hi; i += 64) m = (a[i] > m) ? a[i] : m;
+        return wave_max(m);
+    }
+    __device__ __forceinline__ double arr_min(const double *a, int lo, int hi) const
+    {
+        double m = a[lo];
+        for (int i = lo + lane; i <= hi; i += 64) m = (a[i] < m) ? a[i] : m;
+        return wave_min(m);
+    }
+
+    // edge:800-813 (first = 2), edge:907-918 (first = 1)
+    __device__ __forceinline__ void edge_bounds(int rl, int first)
+    {
+        if (p->double_in) {
+            wb0[rl] = -arr_max(w[1 - rl], first, p->N + 1);
+            wbf[rl] = -w[1 - rl][2];
+        } else {
+            wb0[rl] = p->w_m;
+            wbf[rl] = p->w_m;
+        }
+        if (p->A_c > 0 && rl == 0 && p->N > p->NE) {
+            const double m = arr_min(w[0], p->NE + 2, p->N + 1);
+            wb0[rl] = (m < wb0[rl]) ? m : wb0[rl];
+        }
+    }
+
+    // edge:721-784
+    __device__ __forceinline__ int check_order(int k, double wk, int rl) const
+    {
+        const double *x = w[rl];
+        const int NE = p->NE;
+        const double d0 = p->d0;
+        double d1, d2, d3, d4;
+        if (k == 2) {
+            d1 = x[3] - wk;
+            if (d1 < d0) return 0;
+            if (NE > 2) { d2 = x[4] - x[3]; if (d2 < d1) return 0; }
+        } else if (k == 3) {
+            d1 = wk - x[2];
+            if (d1 < d0) return 0;
+            d2 = -1;
+            if (NE > 2) { d2 = x[4] - wk; if (d2 < d1) return 0; }
+            if (NE > 3) { d3 = x[5] - x[4]; if (d3 < d2) return 0; }
+        } else if (k == NE) {
+            d1 = x[k - 1] - x[k - 2];
+            d2 = wk - x[k - 1];
+            if (d2 < d1) return 0;
+            d3 = x[k + 1] - wk;
+            if (d3 < d2) return 0;
+        } else if (k == NE + 1) {
+            d1 = x[k - 1] - x[k - 2];
+            d2 = wk - x[k - 1];
+            if (d2 < d1) return 0;
+        } else {
+            d1 = x[k - 1] - x[k - 2];
+            d2 = wk - x[k - 1];
+            if (d2 < d1) return 0;
+            d3 = x[k + 1] - wk;
+            if (d3 < d2) return 0;
+            d4 = x[k + 2] - x[k + 1];
+            if (d4 < d3) return 0;
+        }
+        return 1;
+    }
+
+    // one-delta proposal shared by single_edge_move and single_cont_move: evaluate, accept, commit
+    template <bool LOG>
+    __device__ __forceinline__ void try_single(int move, int k, double wk, int rl, double u_acc)
+    {
+        double kn[NTL], gn[NTL];
+        taylor(rl, wk, kn);
+        const double Ak = A[rl][k];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gn[t] = gbar[t] + Ak * (kn[t] - col_get(kcurr[rl], k, t));
+        const double chi2_new = chi2_of(gn);
+        const bool acc = accept_lt(chi2_new, u_acc);
+        if (acc) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) { gbar[t] = gn[t]; col_put(kcurr[rl], k, t, kn[t]); }
+            if (lane == 0) { w[rl][k] = wk; arc[rl][0][k] += 1.0; }
+            commit_chi2(chi2_new);
+            __syncthreads();
+        }
+        rec<LOG>(move, true, acc, chi2_new);
+    }
+
+    // edge:793-885
+    template <bool LOG>
+    __device__ void single_edge_move(int rl)
+    {
+        if (p->A_c == 1) return;
+        edge_bounds(rl, 2);
+        const int NE = p->NE, move = ED_SINGLE + rl;
+        const int k_0 = (p->fix_edge == 1) ? 3 : 2;
+        const double *x = w[rl];
+        for (int i = 1; i <= NE; ++i) {
+            const u32x4 b0 = block((uint32_t)move, (uint32_t)i, 0);
+            int k;
+            if (i % 4 == 0 && p->fix_edge == 0) k = 2;
+            else k = k_0 + index_from_word(b0.x, (uint32_t)(NE + 2 - k_0));
+            const double wk = x[k] + (dwn[rl][k] * (u01(b0.y, b0.z) - 0.5));
+            bool ok = true;
+            if (k == 2 && wk > wb0[rl]) ok = false;
+            if (ok) {
+                if (k < NE + 1) { if (wk < x[k - 1] || wk > x[k + 1]) ok = false; }
+                else { if (wk < x[k - 1] || wk > p->w_m || wk > wbf[rl]) ok = false; }
+            }
+            if (ok) ok = (check_order(k, wk, rl) == 1);
+            if (!ok) { rec<LOG>(move, false, false, 0.0); continue; }
+            const u32x4 b1 = block((uint32_t)move, (uint32_t)i, 1);
+            try_single<LOG>(move, k, wk, rl, u01(b1.x, b1.y));
+        }
+    }
+
+    // ascending sort of tmpd[0..n): rank sort through tmpd2 (values only; ties keep index order)
+    __device__ __forceinline__ void sort_asc(int n)
+    {
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) {
+            const double v = tmpd[e];
+            int r = 0;
+            for (int j = 0; j < n; ++j) {
+                const double o = tmpd[j];
+                r += (o < v || (o == v && j < e)) ? 1 : 0;
+            }
+            tmpd2[r] = v;
+        }
+        __syncthreads();
+        for (int e = lane; e < n; e += 64) tmpd[e] = tmpd2[e];
+        __syncthreads();
+    }
+
+    // edge:973-999
+    __device__ __forceinline__ int multi_1(int n, int rl, uint32_t move, uint32_t iter)
+    {
+        const double *x = w[rl];
+        double *m = mw[rl];
+        const double d1 = x[n + 2] - x[n + 1];
+        const double d0 = p->d0;
+        __syncthreads();
+        for (int u = lane; u < n - 1; u += 64) {          // U_u: block 1 + u/2, words 2(u%2), +1
+            const u32x4 b = block(move, iter, (uint32_t)(1 + u / 2));
+            const double U = (u & 1) ? u01(b.z, b.w) : u01(b.x, b.y);
+            tmpd[u] = d0 + ((d1 - d0) * U);
+        }
+        __syncthreads();
+        double sum = 0.0;
+        for (int i = 0; i < n - 1; ++i) sum = sum + tmpd[i];
+        const double w1 = x[n + 1] - sum;
+        if (!(w1 > p->w_floor[rl] && w1 < wb0[rl])) return 0;
+        if (n > 2) sort_asc(n - 1);
+        double cur = w1;                                   // running position, identical on every lane
+        if (lane == 0) m[2] = w1;
+        for (int i = 2; i <= n; ++i) {
+            cur = cur + tmpd[i - 2];
+            if (lane == 0) m[i + 1] = cur;
+        }
+        __syncthreads();
+        return 1;
+    }
+
+    // edge:1005-1052
+    __device__ __forceinline__ int multi_k(int k, int n, int rl, uint32_t move, uint32_t iter)
+    {
+        const double *x = w[rl];
+        double *m = mw[rl];
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) tmpd[i] = x[k + i + 1] - x[k + i];
+        __syncthreads();
+        const double dk_minus1 = x[k] - x[k - 1];
+        const double dk_plusn = x[k + n + 1] - x[k + n];
+        uint32_t retry = 0;
+        for (int q = 0; q < n / 2; ++q) {
+            const u32x4 b = block(move, iter, (uint32_t)(1 + q));
+            const int i = index_from_word(b.x, (uint32_t)n);
+            int j = index_from_word(b.y, (uint32_t)n);
+            while (j == i) {
+                if (retry > 255) return 0;
+                const u32x4 rb = block(move + (ED_MULTI_RETRY - ED_MULTI), iter, retry++);
+                j = index_from_word(rb.x, (uint32_t)n);
+            }
+            const double di = tmpd[i], dj = tmpd[j];
+            const double a = di + dj - dk_plusn, bb = di + dj - dk_minus1;
+            const double d_min = (dk_minus1 > a) ? dk_minus1 : a;
+            const double d_max = (dk_plusn < bb) ? dk_plusn : bb;
+            const double ni = d_min + (d_max - d_min) * u01(b.z, b.w);
+            const double nj = di + dj - ni;
+            __syncthreads();
+            if (lane == 0) { tmpd[i] = ni; tmpd[j] = nj; }
+            __syncthreads();
+        }
+        sort_asc(n);
+        double cur = x[k];
+        if (lane == 0) m[k] = cur;
+        for (int i = k + 1; i <= k + n - 1; ++i) {
+            cur = cur + tmpd[i - k - 1];
+            if (lane == 0) m[i] = cur;
+        }
+        __syncthreads();
+        return (m[k + n - 1] < wbf[rl]) ? 1 : 0;
+    }
+
+    // edge:889-968
+    template <bool LOG>
+    __device__ void multi_edge_move(int rl)
+    {
+        if (p->A_c == 1) return;
+        const int NE = p->NE;
+        if (NE < 4) return;
+        edge_bounds(rl, 1);
+        const uint32_t move = (uint32_t)(ED_MULTI + rl);
+        for (int i = 0; i <= NE - 1; ++i) {
+            const u32x4 b0 = block(move, (uint32_t)i, 0);
+            int k, n, pass;
+            if (i % 4 == 0 && p->fix_edge == 0) {
+                k = 2;
+                n = nm[rl][2];
+                pass = multi_1(n, rl, move, (uint32_t)i);
+            } else {
+                k = 3 + index_from_word(b0.x, (uint32_t)(NE - 3));
+                n = nm[rl][k];
+                pass = multi_k(k, n, rl, move, (uint32_t)i);
+            }
+            if (pass != 1) { rec<LOG>((int)move, false, false, 0.0); continue; }
+            double gn[NTL];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
+            for (int j = 0; j < n; ++j) {
+                double kn[NTL];
+                taylor(rl, mw[rl][k + j], kn);
+                const double Ak = A[rl][k + j];
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    gn[t] = gn[t] + Ak * (kn[t] - col_get(kcurr[rl], k + j, t));
+                    col_put(knew[rl], k + j, t, kn[t]);
+                }
+            }
+            const double chi2_new = chi2_of(gn);
+            const bool acc = accept_lt(chi2_new, u01(b0.y, b0.z));
+            if (acc) {
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+                for (int j = k; j <= k + n - 1; ++j) {
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) col_put(kcurr[rl], j, t, col_get(knew[rl], j, t));
+                }
+                __syncthreads();
+                for (int j = k + lane; j <= k + n - 1; j += 64) w[rl][j] = mw[rl][j];
+                if (lane == 0) arc[rl][1][k] += 1.0;
+                commit_chi2(chi2_new);
+                __syncthreads();
+            }
+            rec<LOG>((int)move, true, acc, chi2_new);
+        }
+    }
+
+    // amplitude profile of the edge into tempA[2..NE+1], normalised to f1 (edge:1091-1110)
+    __device__ __forceinline__ void edge_profile(int rl, double n1, double eps_prod)
+    {
+        const double c = p->c[rl];
+        const int NE = p->NE;
+        __syncthreads();
+        for (int i = 1 + lane; i <= NE; i += 64) {
+            const double x = log_u01((double)i / n1);
+            const double cx = c * x;
+            const double root = __builtin_sqrt((cx * cx) + eps_prod);
+            const double ln_Ai = (c < 0) ? (cx + root) : (cx - root);
+            tempA[i + 1] = sac_exp(ln_Ai / 2);
+        }
+        __syncthreads();
+        double sum = 0.0;
+        for (int i = 2; i <= NE + 1; ++i) sum = sum + tempA[i];
+        const double f1 = (rl == 0) ? (p->A_r / (1 + p->A_c)) : ((1 - p->A_r) / (1 + p->A_c));
+        const double scale = f1 / sum;
+        __syncthreads();
+        for (int i = 2 + lane; i <= NE + 1; i += 64) tempA[i] = tempA[i] * scale;
+        __syncthreads();
+    }
+
+    // edge:1057-1142
+    template <bool LOG>
+    __device__ void amplitude_edge_move(int rl)
+    {
+        if (p->A_c == 1) return;
+        const int NE = p->NE, move = ED_AMP + rl;
+        if (NE < 3) return;
+        const u32x4 b0 = block((uint32_t)move, 0, 0);
+        const double c = p->c[rl];
+        const double eps = (0.69314718055994530942 * c) * (0.69314718055994530942 * c);
+        double n1 = n0[rl], e1 = eps0[rl];
+        n1 += (dn0[rl] * (u01(b0.x, b0.y) - 0.5));
+        if (n1 < 5 || n1 > (NE - 5)) { rec<LOG>(move, false, false, 0.0); return; }
+        e1 += deps0[rl] * (u01(b0.z, b0.w) - 0.5);
+        if (e1 < 0 || e1 > 1) { rec<LOG>(move, false, false, 0.0); return; }
+        edge_profile(rl, n1, e1 * eps);
+        double gn[NTL], acc_[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc_[t] = 0.0;
+        for (int k = 2; k <= NE + 1; ++k) {                     // edge:1113-1115
+            const double dA = tempA[k] - A[rl][k];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) acc_[t] = acc_[t] + col_get(kcurr[rl], k, t) * dA;
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gn[t] = gbar[t] + acc_[t];
+        const double chi2_new = chi2_of(gn);
+        const u32x4 b1 = block((uint32_t)move, 0, 1);
+        const bool acc = accept_lt(chi2_new, u01(b1.x, b1.y));
+        if (acc) {
+            n0[rl] = n1;
+            eps0[rl] = e1;
+            __syncthreads();
+            for (int k = 2 + lane; k <= NE + 1; k += 64) A[rl][k] = tempA[k];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+            commit_chi2(chi2_new);
+            amp_ar[0][rl] += 1;
+            __syncthreads();
+        }
+        rec<LOG>(move, true, acc, chi2_new);
+    }
+
+    // edge:1146-1189
+    template <bool LOG>
+    __device__ void single_cont_move()
+    {
+        const int NE = p->NE, N = p->N;
+        if (NE == N || p->A_c == 0) return;
+        const double *x = w[0];
+        const double wc_min = x[2], wc_max = x[NE + 1];
+        for (int it = 0; it < N - NE; ++it) {
+            const u32x4 b0 = block(ED_CONT, (uint32_t)it, 0);
+            const int k = NE + 2 + index_from_word(b0.x, (uint32_t)(N - NE));
+            const double wk = x[k] + (dwn[0][k] * (u01(b0.y, b0.z) - 0.5));
+            if (wk < wc_min || wk > wc_max) { rec<LOG>(ED_CONT, false, false, 0.0); continue; }
+            const u32x4 b1 = block(ED_CONT, (uint32_t)it, 1);
+            try_single<LOG>(ED_CONT, k, wk, 0, u01(b1.x, b1.y));
+        }
+    }
+
+    // edge:1194-1252
+    template <bool LOG>
+    __device__ void amplitude_cont_move()
+    {
+        const int NE = p->NE, N = p->N;
+        if (NE == N || p->A_c == 0) return;
+        const int ncand = N - NE - 1;
+        if (ncand < 2) return;
+        int n_accept = 0;
+        for (int i = 1; i <= N; ++i) {
+            const u32x4 b0 = block(ED_CONT_AMP, (uint32_t)i, 0);
+            const int j = NE + 2 + index_from_word(b0.x, (uint32_t)ncand);
+            int k = NE + 2 + index_from_word(b0.y, (uint32_t)ncand);
+            uint32_t retry = 0;
+            bool give_up = false;
+            while (k == j) {
+                if (retry > 255) { give_up = true; break; }
+                const u32x4 rb = block(ED_CONT_AMP_RETRY, (uint32_t)i, retry++);
+                k = NE + 2 + index_from_word(rb.x, (uint32_t)ncand);
+            }
+            if (give_up) { rec<LOG>(ED_CONT_AMP, false, false, 0.0); continue; }
+            const double A_j = A[0][j], A_k = A[0][k];
+            const double m0 = A_j + A_k;
+            const double r = u01(b0.z, b0.w);
+            const double dA_j = (r * m0) - A_j;
+            const double dA_k = ((1 - r) * m0) - A_k;
+            double gn[NTL];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+                gn[t] = (gbar[t] + dA_j * col_get(kcurr[0], j, t)) + dA_k * col_get(kcurr[0], k, t);
+            const double chi2_new = chi2_of(gn);
+            const u32x4 b1 = block(ED_CONT_AMP, (uint32_t)i, 1);
+            const bool acc = accept_lt(chi2_new, u01(b1.x, b1.y));
+            if (acc) {
+                __syncthreads();
+                if (lane == 0) { A[0][j] = A_j + dA_j; A[0][k] = A_k + dA_k; }
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+                commit_chi2(chi2_new);
+                n_accept += 1;
+                __syncthreads();
+            }
+            rec<LOG>(ED_CONT_AMP, true, acc, chi2_new);
+        }
+        amp_ar[1][0] += (double)n_accept / (double)(N - NE);
+    }
+};
+
+}  // namespace sacdev

@@ -1,0 +1,903 @@
+// libsac_hip.so, edge parameterisation: stage kernel + C ABI (sac_edge_* in include/sac_hip.h).
+// "edge:NNN" = /root/reference/sac/edge/sac_edge.jl line NNN.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "../../include/sac_hip.h"
+#include "edge_sweep.h"
+
+using namespace sacdev;
+
+int sac_internal_fail(int code, const char *msg);   // sac_hip.hip
+
+namespace {
+
+int efail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return sac_internal_fail(code, buf);
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return efail(SAC_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                              \
+    } while (0)
+
+// LDS bytes of one chain: 15 double arrays + 3 int arrays of S entries
+constexpr size_t edge_lds_bytes(int S) { return (size_t)S * (15u * 8u + 3u * 4u) + 64u; }
+
+}  // namespace
+
+// One launch = n_sweeps sweeps of run_updates (edge:1260-1302) for every chain; by flag the
+// start-of-bin work (zero the bin accumulators and accept counters, Gbar = K_curr A) and the
+// end-of-bin work (record_bin, check_w, adjust_D).  One wave = one chain.
+template <int NTL, bool LOG>
+__global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
+{
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const int chain = (int)blockIdx.x;
+    const int lane = lane_id();
+    const int S = p.S, N = p.N, NE = p.NE;
+    EdgeChain<NTL> c;
+    c.p = &p;
+    c.lane = lane;
+    c.chain = chain;
+    {
+        double *d = reinterpret_cast<double *>(s_dyn);
+        for (int rl = 0; rl < 2; ++rl) {
+            c.w[rl] = d; d += S;
+            c.A[rl] = d; d += S;
+            c.dwn[rl] = d; d += S;
+            c.mw[rl] = d; d += S;
+            c.arc[rl][0] = d; d += S;
+            c.arc[rl][1] = d; d += S;
+        }
+        c.tmpd = d; d += S;
+        c.tmpd2 = d; d += S;
+        c.tempA = d; d += S;
+        int *ip = reinterpret_cast<int *>(d);
+        c.nm[0] = ip; ip += S;
+        c.nm[1] = ip; ip += S;
+        c.bins = ip;
+    }
+    const size_t cs = (size_t)chain * 2u * (size_t)S;
+    for (int rl = 0; rl < 2; ++rl) {
+        const size_t o = cs + (size_t)rl * S;
+        for (int k = lane; k < S; k += 64) {
+            c.w[rl][k] = p.w[o + k];
+            c.A[rl][k] = p.A[o + k];
+            c.dwn[rl][k] = p.dw[o + k];
+            c.mw[rl][k] = p.mw[o + k];
+            c.nm[rl][k] = p.nm[o + k];
+            c.arc[rl][0][k] = p.arc[(cs + (size_t)rl * S) * 2u + k];
+            c.arc[rl][1][k] = p.arc[(cs + (size_t)rl * S) * 2u + S + k];
+        }
+        c.kcurr[rl] = p.kcurr + (cs + (size_t)rl * S) * (size_t)p.ntp;
+        c.knew[rl] = p.knew + (cs + (size_t)rl * S) * (size_t)p.ntp;
+    }
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        c.off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        c.gbar[t] = gbar_g[j];
+        c.G[t] = p.G[j];
+        c.sinv[t] = p.sinv[j];
+    }
+    EdgeScalars *scp = p.sc + chain;
+    c.chi2 = scp->chi2;
+    c.chi2_min = scp->chi2_min;
+    for (int rl = 0; rl < 2; ++rl) {
+        c.n0[rl] = scp->n0[rl]; c.eps0[rl] = scp->eps0[rl]; c.dn0[rl] = scp->dn0[rl]; c.deps0[rl] = scp->deps0[rl];
+        for (int m = 0; m < 3; ++m) c.amp_ar[m][rl] = scp->amp_ar[m][rl];
+        c.wb0[rl] = c.wbf[rl] = p.w_m;
+    }
+    double chi2_acc = scp->chi2_res[0];
+    double edge_acc[2] = {scp->edge_res[0][0], scp->edge_res[0][1]};
+    double n0_acc[2] = {scp->n0_res[0][0], scp->n0_res[0][1]};
+    double wn0_acc[2] = {scp->wn0_res[0][0], scp->wn0_res[0][1]};
+    unsigned long long sweep = scp->sweep;
+    c.inv2theta = p.inv2theta;
+    c.chain_id = p.chain_offset + (uint32_t)chain;
+    c.n_prop = c.n_eval = c.n_acc = c.n_cols = 0;
+    c.log = nullptr;
+    c.log_cap = 0;
+    c.log_pos = 0;
+    if constexpr (LOG) {
+        if (chain == p.log_chain) { c.log = p.log; c.log_cap = p.log_cap; c.log_pos = *p.log_len; }
+    }
+    __syncthreads();
+
+    if (p.flags & EDGE_BIN_START) {                       // edge:1263-1270
+        chi2_acc = 0.0;
+        for (int rl = 0; rl < 2; ++rl) {
+            edge_acc[rl] = 0.0; n0_acc[rl] = 0.0; wn0_acc[rl] = 0.0;
+            for (int k = lane; k < S; k += 64) { c.arc[rl][0][k] = 0.0; c.arc[rl][1][k] = 0.0; }
+        }
+        __syncthreads();
+        double acc[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[t] = 0.0;
+        for (int k = 1; k <= N + 1; ++k) {                // calc_Gbar!(self, 0), edge:615
+            const double Ak = c.A[0][k];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) acc[t] = acc[t] + c.col_get(c.kcurr[0], k, t) * Ak;
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) c.gbar[t] = acc[t];
+        if (p.n_rl == 2) {                                // edge:618-620
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) acc[t] = 0.0;
+            for (int k = 1; k <= N + 1; ++k) {
+                const double Ak = c.A[1][k];
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) acc[t] = acc[t] + c.col_get(c.kcurr[1], k, t) * Ak;
+            }
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) c.gbar[t] = c.gbar[t] + acc[t];
+        }
+    }
+
+    double *hist = p.hist + (size_t)(chain % p.hist_copies) * 4u * (size_t)p.n_grid;
+    for (int s = 0; s < p.n_sweeps; ++s) {
+        c.sweep_lo = (uint32_t)sweep;
+        c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
+        for (int rl = 0; rl < p.n_rl; ++rl) {             // edge:1273-1281
+            c.template single_edge_move<LOG>(rl);
+            c.template multi_edge_move<LOG>(rl);
+            c.template amplitude_edge_move<LOG>(rl);
+        }
+        if (p.A_c > 0) {                                  // edge:1283-1287
+            c.template single_cont_move<LOG>();
+            c.template amplitude_cont_move<LOG>();
+        }
+        // measure (edge:1305-1333)
+        chi2_acc += c.chi2;
+        for (int rl = 0; rl < p.n_rl; ++rl) {
+            n0_acc[rl] += c.n0[rl] / NE;
+            int idx = (int)__builtin_floor(c.n0[rl]);
+            idx = idx < 1 ? 1 : (idx > N + 1 ? N + 1 : idx);
+            wn0_acc[rl] += c.w[rl][idx];
+            edge_acc[rl] += c.w[rl][2];
+            double *wavg = p.wavg + cs + (size_t)rl * S, *aavg = p.aavg + cs + (size_t)rl * S;
+            for (int k = 1 + lane; k <= N + 1; k += 64) {
+                aavg[k] += c.A[rl][k];
+                wavg[k] += c.w[rl][k];
+            }
+            // histograms: bin of delta i (1..N) at Julia index i+1; -1 = outside the grid
+            for (int i = 1 + lane; i <= N; i += 64) {
+                const long long wi = (long long)__builtin_floor(c.w[rl][i + 1] / p.dwg) - p.wi0;
+                c.bins[i] = (wi < 0 || wi >= p.n_grid) ? -1 : (int)wi;
+            }
+            __syncthreads();
+            for (int i = 1 + lane; i <= N; i += 64) {
+                const int b = c.bins[i];
+                if (b < 0) continue;
+                const int lo = (i <= NE) ? 1 : NE + 1, hi = (i <= NE) ? NE : N;
+                double *dst = hist + ((size_t)rl * 2u + (i <= NE ? 0u : 1u)) * (size_t)p.n_grid + b;
+                if (p.hist_exclusive) {
+                    // the first delta of a bin adds the bin's deltas in index order (= the reference's loop order)
+                    bool head = true;
+                    for (int j = lo; j < i; ++j) head = head && (c.bins[j] != b);
+                    if (!head) continue;
+                    double v = *dst;
+                    for (int j = i; j <= hi; ++j)
+                        if (c.bins[j] == b) v = v + c.A[rl][j + 1];
+                    *dst = v;
+                } else {
+                    unsafeAtomicAdd(dst, c.A[rl][i + 1]);
+                }
+            }
+            __syncthreads();
+        }
+        sweep += 1;
+    }
+
+    unsigned long long viol = 0;
+    if (p.flags & EDGE_BIN_END) {
+        const double steps = p.steps_in_bin;
+        // record_bin (edge:1337-1353)
+        chi2_acc /= steps;
+        const double c1 = chi2_acc;
+        if (lane == 0) {
+            scp->chi2_res[1] += c1;
+            scp->chi2_res[2] += c1 * c1;
+        }
+        for (int rl = 0; rl < 2; ++rl) {
+            n0_acc[rl] /= steps; wn0_acc[rl] /= steps; edge_acc[rl] /= steps;
+            if (lane == 0) {
+                scp->n0_res[1][rl] += n0_acc[rl];
+                scp->wn0_res[1][rl] += wn0_acc[rl];
+                scp->edge_res[1][rl] += edge_acc[rl];
+                scp->n0_res[2][rl] += n0_acc[rl] * n0_acc[rl];
+                scp->wn0_res[2][rl] += wn0_acc[rl] * wn0_acc[rl];
+                scp->edge_res[2][rl] += edge_acc[rl] * edge_acc[rl];
+            }
+        }
+        // check_w (edge:658-718), counted instead of exit()
+        for (int rl = 0; rl < p.n_rl; ++rl) {
+            const double *x = c.w[rl];
+            bool bad = false;
+            if (x[2] < p.w_floor[rl]) bad = true;
+            if (c.arr_min(x, 1, N + 1) < p.w_floor[rl] || c.arr_max(x, 1, N + 1) > p.w_m) bad = true;
+            if (NE < N && rl == 0 && x[2] > c.arr_min(x, NE + 2, N + 1)) bad = true;
+            if (x[3] - x[2] < p.d0) bad = true;
+            double worst = 0.0;
+            for (int i = 2 + lane; i <= NE - 1; i += 64) {
+                const double v1 = x[i + 1] - x[i], v2 = x[i + 2] - x[i + 1];
+                if (v2 < v1 && v1 - v2 > worst) worst = v1 - v2;
+            }
+            if (wave_max(worst) > 1e-10) bad = true;
+            viol += bad ? 1 : 0;
+        }
+        // adjust_D (edge:1384-1432)
+        __syncthreads();
+        for (int rl = 0; rl < p.n_rl; ++rl) {
+            for (int k = 1 + lane; k <= N + 1; k += 64) {
+                c.arc[rl][0][k] /= steps;
+                c.arc[rl][1][k] /= steps;
+            }
+            __syncthreads();
+            for (int i = 1 + lane; i <= N; i += 64) {
+                if (c.arc[rl][0][i + 1] > 0.55) c.dwn[rl][i + 1] *= 1.25;
+                else if (c.arc[rl][0][i + 1] < 0.45) c.dwn[rl][i + 1] /= 1.2;
+            }
+            for (int i = lane; i <= NE - 2; i += 64) {
+                if (c.arc[rl][1][i + 1] > 0.55)
+                    c.nm[rl][i + 1] = (int)__builtin_floor((double)c.nm[rl][i + 1] * 1.25) + 1;
+                else if (c.arc[rl][1][i + 1] < 0.45) {
+                    const int v = (int)__builtin_floor((double)c.nm[rl][i + 1] / 1.2);
+                    c.nm[rl][i + 1] = v > 1 ? v : 1;
+                }
+            }
+            __syncthreads();
+            if (NE > 3)
+                for (int i = 2 + lane; i <= NE - 1; i += 64)
+                    if (c.nm[rl][i] > NE - i) c.nm[rl][i] = NE - i;
+            c.amp_ar[0][rl] /= steps;
+            c.amp_ar[1][rl] /= steps;
+            if (c.amp_ar[0][rl] > 0.55) { c.dn0[rl] *= 1.25; c.deps0[rl] *= 1.25; }
+            else if (c.amp_ar[0][rl] < 0.45) { c.dn0[rl] /= 1.20; c.deps0[rl] /= 1.20; }
+        }
+        __syncthreads();
+    }
+
+    // write back
+    for (int rl = 0; rl < 2; ++rl) {
+        const size_t o = cs + (size_t)rl * S;
+        for (int k = lane; k < S; k += 64) {
+            p.w[o + k] = c.w[rl][k];
+            p.A[o + k] = c.A[rl][k];
+            p.dw[o + k] = c.dwn[rl][k];
+            p.mw[o + k] = c.mw[rl][k];
+            p.nm[o + k] = c.nm[rl][k];
+            p.arc[o * 2u + k] = c.arc[rl][0][k];
+            p.arc[o * 2u + S + k] = c.arc[rl][1][k];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        if (j < p.n_tau) gbar_g[j] = c.gbar[t];
+    }
+    if (lane == 0) {
+        scp->chi2 = c.chi2;
+        scp->chi2_min = c.chi2_min;
+        for (int rl = 0; rl < 2; ++rl) {
+            scp->n0[rl] = c.n0[rl]; scp->eps0[rl] = c.eps0[rl]; scp->dn0[rl] = c.dn0[rl]; scp->deps0[rl] = c.deps0[rl];
+            for (int m = 0; m < 3; ++m) scp->amp_ar[m][rl] = c.amp_ar[m][rl];
+            scp->edge_res[0][rl] = edge_acc[rl];
+            scp->n0_res[0][rl] = n0_acc[rl];
+            scp->wn0_res[0][rl] = wn0_acc[rl];
+        }
+        scp->chi2_res[0] = chi2_acc;
+        scp->sweep = sweep;
+        scp->counters[0] += c.n_prop;
+        scp->counters[1] += c.n_eval;
+        scp->counters[2] += c.n_acc;
+        scp->counters[4] += c.n_cols;
+        scp->violations += viol;
+        if constexpr (LOG) {
+            if (c.log != nullptr) *p.log_len = c.log_pos;
+        }
+    }
+}
+
+// calc_Gbar!(self, 1); chi2 = calc_chi2; chi2_min = chi2  (edge:559-561, 1728-1730)
+template <int NTL>
+__global__ void __launch_bounds__(64) edge_init_kernel(const EdgeParams p)
+{
+    const int chain = (int)blockIdx.x, lane = lane_id();
+    const int S = p.S, N = p.N;
+    EdgeChain<NTL> c;
+    c.p = &p;
+    c.lane = lane;
+    c.n_cols = 0;
+    const size_t cs = (size_t)chain * 2u * (size_t)S;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        c.off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        c.G[t] = p.G[j];
+        c.sinv[t] = p.sinv[j];
+        c.gbar[t] = 0.0;
+    }
+    for (int rl = 0; rl < p.n_rl; ++rl) {
+        double *kc = p.kcurr + (cs + (size_t)rl * S) * (size_t)p.ntp;
+        const double *w = p.w + cs + (size_t)rl * S, *A = p.A + cs + (size_t)rl * S;
+        double acc[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) acc[t] = 0.0;
+        for (int k = 1; k <= N + 1; ++k) {
+            double kn[NTL];
+            c.taylor(rl, w[k], kn);
+            const double Ak = A[k];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                c.col_put(kc, k, t, kn[t]);
+                acc[t] = acc[t] + kn[t] * Ak;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) c.gbar[t] = (rl == 0) ? acc[t] : c.gbar[t] + acc[t];
+    }
+    const double chi2 = c.chi2_of(c.gbar);
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        gbar_g[j] = (j < p.n_tau) ? c.gbar[t] : 0.0;
+    }
+    if (lane == 0) {
+        p.sc[chain].chi2 = chi2;
+        p.sc[chain].chi2_min = chi2;
+    }
+}
+
+// =========================================================================================
+// Host side
+// =========================================================================================
+
+struct sac_edge {
+    sac_edge_config_t cfg{};
+    int ntp = 0, S = 0, hist_copies = 1;
+    bool hist_exclusive = false;
+    int sweeps_per_launch = 64;
+    double *dTab[2] = {nullptr, nullptr};
+    double *dG = nullptr, *dSinv = nullptr;
+    double *dW = nullptr, *dA = nullptr, *dDw = nullptr, *dMw = nullptr, *dArc = nullptr;
+    int *dNm = nullptr;
+    double *dKcurr = nullptr, *dKnew = nullptr, *dGbar = nullptr, *dWavg = nullptr, *dAavg = nullptr, *dHist = nullptr;
+    EdgeScalars *dSc = nullptr;
+    MoveRec *dLog = nullptr;
+    unsigned long long *dLogLen = nullptr;
+    long long log_cap = 0;
+    int log_chain = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool problem = false, state_set = false, gbar_set = false;
+    int64_t last_steps = 0, last_bins = 0;
+    double last_stage_ms = 0.0;
+};
+
+static int use_device(sac_edge *h)
+{
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return SAC_OK;
+}
+
+static void fill_params(const sac_edge *h, EdgeParams &p)
+{
+    std::memset(&p, 0, sizeof(p));
+    const sac_edge_config_t &c = h->cfg;
+    p.tab[0] = h->dTab[0]; p.tab[1] = h->dTab[1];
+    p.G = h->dG; p.sinv = h->dSinv;
+    p.w = h->dW; p.A = h->dA; p.dw = h->dDw; p.mw = h->dMw; p.nm = h->dNm; p.arc = h->dArc;
+    p.kcurr = h->dKcurr; p.knew = h->dKnew; p.gbar = h->dGbar; p.wavg = h->dWavg; p.aavg = h->dAavg;
+    p.hist = h->dHist; p.sc = h->dSc;
+    p.log = h->dLog; p.log_len = h->dLogLen; p.log_cap = h->log_cap; p.log_chain = h->log_chain;
+    p.n_chains = c.n_chains; p.n_tau = c.n_tau; p.ntp = h->ntp; p.NE = c.n_e; p.N = c.n_omega; p.S = h->S;
+    p.n_rl = c.n_rl; p.double_in = c.double_in; p.fix_edge = c.fix_edge;
+    p.hist_copies = h->hist_copies; p.hist_exclusive = h->hist_exclusive ? 1 : 0;
+    p.n_grid = c.n_grid; p.wi0 = c.wi_0;
+    p.A_c = c.A_c; p.A_r = c.A_r; p.d0 = c.d0; p.w_floor[0] = c.w_floor[0]; p.w_floor[1] = c.w_floor[1];
+    p.w_m = c.w_m; p.dwg = c.d_omega; p.c[0] = c.c[0]; p.c[1] = c.c[1];
+    p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32); p.chain_offset = c.chain_offset;
+}
+
+extern "C" int sac_edge_create(const sac_edge_config_t *cfg, sac_edge_t **out)
+{
+    if (!cfg || !out) return efail(SAC_E_INVALID, "sac_edge_create: null argument");
+    *out = nullptr;
+    if (cfg->n_tau < 1 || cfg->n_tau > SAC_MAX_N_TAU)
+        return efail(SAC_E_INVALID, "sac_edge_create: n_tau=%d outside 1..%d", cfg->n_tau, SAC_MAX_N_TAU);
+    if (cfg->n_e < 4 || cfg->n_e > SAC_MAX_N_EDGE)
+        return efail(SAC_E_INVALID, "sac_edge_create: n_e=%d outside 4..%d", cfg->n_e, SAC_MAX_N_EDGE);
+    if (cfg->n_omega < cfg->n_e || cfg->n_omega > 2 * SAC_MAX_N_EDGE)
+        return efail(SAC_E_INVALID, "sac_edge_create: n_omega=%d outside n_e..%d", cfg->n_omega, 2 * SAC_MAX_N_EDGE);
+    if (cfg->n_rl < 1 || cfg->n_rl > 2) return efail(SAC_E_INVALID, "sac_edge_create: n_rl=%d", cfg->n_rl);
+    if (cfg->double_in && cfg->n_rl != 2) return efail(SAC_E_INVALID, "sac_edge_create: double_in needs n_rl = 2");
+    if (cfg->n_chains < 1) return efail(SAC_E_INVALID, "sac_edge_create: n_chains=%d", cfg->n_chains);
+    if (cfg->n_grid < 2 || cfg->n_grid > (1ll << 30))
+        return efail(SAC_E_INVALID, "sac_edge_create: n_grid=%lld outside 2..2^30", (long long)cfg->n_grid);
+    if (!(cfg->d_omega > 0)) return efail(SAC_E_INVALID, "sac_edge_create: d_omega must be positive");
+    if (cfg->A_c < 0 || cfg->A_c >= 1) return efail(SAC_E_INVALID, "sac_edge_create: A_c=%g outside [0,1)", cfg->A_c);
+    if (cfg->A_c > 0 && cfg->n_omega == cfg->n_e)
+        return efail(SAC_E_INVALID, "sac_edge_create: A_c > 0 needs continuum deltas (n_omega > n_e)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return efail(SAC_E_INVALID, "sac_edge_create: device %d of %d", cfg->device, ndev);
+    sac_edge *h = new (std::nothrow) sac_edge();
+    if (!h) return efail(SAC_E_NOMEM, "sac_edge_create: out of host memory");
+    h->cfg = *cfg;
+    h->ntp = (cfg->n_tau + 7) / 8 * 8;
+    h->S = (cfg->n_omega + 3 + 7) / 8 * 8;
+    if (cfg->sweeps_per_launch > 0) h->sweeps_per_launch = cfg->sweeps_per_launch;
+    h->hist_copies = cfg->hist_copies > 0 ? cfg->hist_copies : 1;
+    if (h->hist_copies > cfg->n_chains) h->hist_copies = cfg->n_chains;
+    h->hist_exclusive = (h->hist_copies == cfg->n_chains);
+    int rc = use_device(h);
+    if (rc) { delete h; return rc; }
+    const size_t nc = (size_t)cfg->n_chains, S = (size_t)h->S;
+#define EALLOC(ptr, bytes)                                                           \
+    do {                                                                             \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                         \
+        if (e_ == hipSuccess) e_ = hipMemset((ptr), 0, (bytes));                     \
+        if (e_ != hipSuccess) {                                                      \
+            sac_edge_destroy(h);                                                     \
+            return efail(SAC_E_HIP, "sac_edge_create: allocating %zu bytes: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                                            \
+    } while (0)
+    EALLOC(h->dG, SAC_MAX_N_TAU * sizeof(double));
+    EALLOC(h->dSinv, SAC_MAX_N_TAU * sizeof(double));
+    EALLOC(h->dW, nc * 2 * S * sizeof(double));
+    EALLOC(h->dA, nc * 2 * S * sizeof(double));
+    EALLOC(h->dDw, nc * 2 * S * sizeof(double));
+    EALLOC(h->dMw, nc * 2 * S * sizeof(double));
+    EALLOC(h->dNm, nc * 2 * S * sizeof(int));
+    EALLOC(h->dArc, nc * 4 * S * sizeof(double));
+    EALLOC(h->dKcurr, nc * 2 * S * (size_t)h->ntp * sizeof(double));
+    EALLOC(h->dKnew, nc * 2 * S * (size_t)h->ntp * sizeof(double));
+    EALLOC(h->dGbar, nc * SAC_MAX_N_TAU * sizeof(double));
+    EALLOC(h->dWavg, nc * 2 * S * sizeof(double));
+    EALLOC(h->dAavg, nc * 2 * S * sizeof(double));
+    EALLOC(h->dHist, (size_t)h->hist_copies * 4 * (size_t)cfg->n_grid * sizeof(double));
+    EALLOC(h->dSc, nc * sizeof(EdgeScalars));
+    EALLOC(h->dLogLen, sizeof(unsigned long long));
+#undef EALLOC
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+        hipEventCreate(&h->ev1) != hipSuccess) {
+        sac_edge_destroy(h);
+        return efail(SAC_E_HIP, "sac_edge_create: stream/event creation failed");
+    }
+    *out = h;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_destroy(sac_edge_t *h)
+{
+    if (!h) return SAC_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->dTab[0], h->dTab[1], h->dG, h->dSinv, h->dW, h->dA, h->dDw, h->dMw, h->dNm, h->dArc, h->dKcurr,
+                    h->dKnew, h->dGbar, h->dWavg, h->dAavg, h->dHist, h->dSc, h->dLog, h->dLogLen};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_upload_problem(sac_edge_t *h, const double *const *K, const double *const *dK,
+                                       const double *const *d2K, const double *G, const double *sigma_inv)
+{
+    if (!h || !K || !dK || !d2K || !G || !sigma_inv) return efail(SAC_E_INVALID, "sac_edge_upload_problem: null argument");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const size_t ng = (size_t)h->cfg.n_grid, nt = (size_t)h->cfg.n_tau, ntp = (size_t)h->ntp;
+    const size_t CH = 16384;                              // columns per staging chunk
+    std::vector<double> stage(CH * 3 * ntp);
+    for (int rl = 0; rl < h->cfg.n_rl; ++rl) {
+        if (!K[rl] || !dK[rl] || !d2K[rl]) return efail(SAC_E_INVALID, "sac_edge_upload_problem: null table for side %d", rl);
+        if (!h->dTab[rl]) HIP_TRY(hipMalloc((void **)&h->dTab[rl], ng * 3 * ntp * sizeof(double)));
+        for (size_t a = 0; a < ng; a += CH) {
+            const size_t n = (ng - a < CH) ? ng - a : CH;
+            std::fill(stage.begin(), stage.begin() + n * 3 * ntp, 0.0);
+            const double *src[3] = {K[rl], dK[rl], d2K[rl]};
+            for (size_t i = 0; i < n; ++i)
+                for (int q = 0; q < 3; ++q)
+                    std::memcpy(&stage[(i * 3 + q) * ntp], src[q] + (a + i) * nt, nt * sizeof(double));
+            HIP_TRY(hipMemcpy(h->dTab[rl] + a * 3 * ntp, stage.data(), n * 3 * ntp * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    double pad[SAC_MAX_N_TAU];
+    std::memset(pad, 0, sizeof(pad));
+    std::memcpy(pad, G, nt * sizeof(double));
+    HIP_TRY(hipMemcpy(h->dG, pad, sizeof(pad), hipMemcpyHostToDevice));
+    std::memset(pad, 0, sizeof(pad));
+    std::memcpy(pad, sigma_inv, nt * sizeof(double));
+    HIP_TRY(hipMemcpy(h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
+    h->problem = true;
+    return SAC_OK;
+}
+
+// arrays in the reference's shape [N_w+1, 2] (column-major: side after side)
+extern "C" int sac_edge_set_state(sac_edge_t *h, int32_t chain, const double *w, const double *A, const double *dw,
+                                  const int64_t *n_multi, const double *scal8)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_set_state: null handle");
+    const int nc = h->cfg.n_chains, n1 = h->cfg.n_omega + 1, NE = h->cfg.n_e, S = h->S;
+    if (chain < -1 || chain >= nc) return efail(SAC_E_INVALID, "sac_edge_set_state: chain %d outside -1..%d", chain, nc - 1);
+    if (n_multi)
+        for (int rl = 0; rl < h->cfg.n_rl; ++rl)
+            for (int k = 2; k <= NE - 1; ++k) {
+                const int64_t v = n_multi[rl * n1 + k - 1];
+                if (v < 0 || v > NE - k)
+                    return efail(SAC_E_INVALID, "sac_edge_set_state: n_multi[%d, side %d] = %lld outside 0..%d", k, rl + 1,
+                                 (long long)v, NE - k);
+            }
+    if (w)
+        for (int i = 0; i < 2 * n1; ++i)
+            if (!std::isfinite(w[i])) return efail(SAC_E_INVALID, "sac_edge_set_state: non-finite frequency");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
+    auto put_d = [&](double *dst, const double *src) -> int {
+        std::vector<double> one(2 * (size_t)S, 0.0);
+        for (int rl = 0; rl < 2; ++rl)
+            for (int k = 1; k <= n1; ++k) one[(size_t)rl * S + k] = src[rl * n1 + k - 1];
+        std::vector<double> all((size_t)count * one.size());
+        for (int c = 0; c < count; ++c) std::memcpy(all.data() + (size_t)c * one.size(), one.data(), one.size() * sizeof(double));
+        HIP_TRY(hipMemcpy(dst + (size_t)first * one.size(), all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
+        return SAC_OK;
+    };
+    if (w && (rc = put_d(h->dW, w))) return rc;
+    if (A && (rc = put_d(h->dA, A))) return rc;
+    if (dw && (rc = put_d(h->dDw, dw))) return rc;
+    if (n_multi) {
+        std::vector<int> one(2 * (size_t)S, 0);
+        for (int rl = 0; rl < 2; ++rl)
+            for (int k = 1; k <= n1; ++k) one[(size_t)rl * S + k] = (int)n_multi[rl * n1 + k - 1];
+        std::vector<int> all((size_t)count * one.size());
+        for (int c = 0; c < count; ++c) std::memcpy(all.data() + (size_t)c * one.size(), one.data(), one.size() * sizeof(int));
+        HIP_TRY(hipMemcpy(h->dNm + (size_t)first * one.size(), all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    if (scal8) {
+        std::vector<EdgeScalars> sc((size_t)count);
+        HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
+        for (auto &s : sc)
+            for (int rl = 0; rl < 2; ++rl) {
+                s.n0[rl] = scal8[rl]; s.eps0[rl] = scal8[2 + rl]; s.dn0[rl] = scal8[4 + rl]; s.deps0[rl] = scal8[6 + rl];
+            }
+        HIP_TRY(hipMemcpy(h->dSc + first, sc.data(), sc.size() * sizeof(EdgeScalars), hipMemcpyHostToDevice));
+    }
+    if (w && A) h->state_set = true;
+    if (w || A) h->gbar_set = false;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_state(sac_edge_t *h, int32_t chain, double *w, double *A, double *dw, int64_t *n_multi,
+                                  double *scal8)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_get_state: null handle");
+    const int nc = h->cfg.n_chains, n1 = h->cfg.n_omega + 1, S = h->S;
+    if (chain < 0 || chain >= nc) return efail(SAC_E_INVALID, "sac_edge_get_state: chain %d outside 0..%d", chain, nc - 1);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<double> one(2 * (size_t)S);
+    auto get_d = [&](const double *src, double *dst) -> int {
+        HIP_TRY(hipMemcpy(one.data(), src + (size_t)chain * one.size(), one.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int rl = 0; rl < 2; ++rl)
+            for (int k = 1; k <= n1; ++k) dst[rl * n1 + k - 1] = one[(size_t)rl * S + k];
+        return SAC_OK;
+    };
+    if (w && (rc = get_d(h->dW, w))) return rc;
+    if (A && (rc = get_d(h->dA, A))) return rc;
+    if (dw && (rc = get_d(h->dDw, dw))) return rc;
+    if (n_multi) {
+        std::vector<int> oi(2 * (size_t)S);
+        HIP_TRY(hipMemcpy(oi.data(), h->dNm + (size_t)chain * oi.size(), oi.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int rl = 0; rl < 2; ++rl)
+            for (int k = 1; k <= n1; ++k) n_multi[rl * n1 + k - 1] = oi[(size_t)rl * S + k];
+    }
+    if (scal8) {
+        EdgeScalars s;
+        HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        for (int rl = 0; rl < 2; ++rl) {
+            scal8[rl] = s.n0[rl]; scal8[2 + rl] = s.eps0[rl]; scal8[4 + rl] = s.dn0[rl]; scal8[6 + rl] = s.deps0[rl];
+        }
+    }
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_init_gbar(sac_edge_t *h)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_init_gbar: null handle");
+    if (!h->problem || !h->state_set) return efail(SAC_E_STATE, "sac_edge_init_gbar: upload the problem and set the state first");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    EdgeParams p;
+    fill_params(h, p);
+    const dim3 grid((unsigned)h->cfg.n_chains), block(64);
+    if (h->cfg.n_tau <= 64) hipLaunchKernelGGL(edge_init_kernel<1>, grid, block, 0, h->stream, p);
+    else hipLaunchKernelGGL(edge_init_kernel<2>, grid, block, 0, h->stream, p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->gbar_set = true;
+    return SAC_OK;
+}
+
+static int launch_stage(sac_edge *h, EdgeParams &p)
+{
+    const bool log = (h->log_chain >= 0 && h->dLog != nullptr);
+    const dim3 grid((unsigned)h->cfg.n_chains), block(64);
+    const size_t lds = edge_lds_bytes(h->S);
+    const int variant = (h->cfg.n_tau <= 64 ? 0 : 2) | (log ? 1 : 0);
+#define SAC_ELAUNCH(NTL_, LOG_)                                                                          \
+    do {                                                                                                 \
+        if (lds > 48 * 1024)                                                                             \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&edge_stage_kernel<NTL_, LOG_>),  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL((edge_stage_kernel<NTL_, LOG_>), grid, block, lds, h->stream, p);             \
+    } while (0)
+    switch (variant) {
+    case 0: SAC_ELAUNCH(1, false); break;
+    case 1: SAC_ELAUNCH(1, true); break;
+    case 2: SAC_ELAUNCH(2, false); break;
+    default: SAC_ELAUNCH(2, true); break;
+    }
+#undef SAC_ELAUNCH
+    HIP_TRY(hipGetLastError());
+    return SAC_OK;
+}
+
+// run_bins(self, steps, bins, theta)  edge:1357-1379 (bin_averages is applied by sac_edge_get_results)
+extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, double theta)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_run_bins: null handle");
+    if (!h->problem || !h->state_set || !h->gbar_set)
+        return efail(SAC_E_STATE, "sac_edge_run_bins: problem, state and Gbar must be set first");
+    if (steps < 1 || bins < 2) return efail(SAC_E_INVALID, "sac_edge_run_bins: steps=%lld bins=%lld (>= 1, >= 2)", (long long)steps, (long long)bins);
+    if (!(theta > 0) || !std::isfinite(theta)) return efail(SAC_E_INVALID, "sac_edge_run_bins: theta=%g", theta);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const size_t nc = (size_t)h->cfg.n_chains, S = (size_t)h->S;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    // edge:1359-1365: zero the results, spectra and averages
+    {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::vector<EdgeScalars> sc(nc);
+        HIP_TRY(hipMemcpy(sc.data(), h->dSc, nc * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
+        for (auto &s : sc) {
+            std::memset(s.chi2_res, 0, sizeof(s.chi2_res));
+            std::memset(s.edge_res, 0, sizeof(s.edge_res));
+            std::memset(s.n0_res, 0, sizeof(s.n0_res));
+            std::memset(s.wn0_res, 0, sizeof(s.wn0_res));
+        }
+        HIP_TRY(hipMemcpy(h->dSc, sc.data(), nc * sizeof(EdgeScalars), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * 4 * (size_t)h->cfg.n_grid * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->dWavg, 0, nc * 2 * S * sizeof(double), h->stream));
+    HIP_TRY(hipMemsetAsync(h->dAavg, 0, nc * 2 * S * sizeof(double), h->stream));
+    EdgeParams p;
+    fill_params(h, p);
+    p.inv2theta = 1.0 / (2.0 * theta);
+    p.steps_in_bin = (double)steps;
+    for (int64_t b = 0; b < bins; ++b) {
+        int64_t done = 0;
+        while (done < steps) {
+            int64_t chunk = steps - done;
+            if (chunk > h->sweeps_per_launch) chunk = h->sweeps_per_launch;
+            p.n_sweeps = (int)chunk;
+            p.flags = (done == 0 ? EDGE_BIN_START : 0) | (done + chunk >= steps ? EDGE_BIN_END : 0);
+            if ((rc = launch_stage(h, p))) return rc;
+            done += chunk;
+        }
+    }
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->last_stage_ms = ms;
+    h->last_steps = steps;
+    h->last_bins = bins;
+    return SAC_OK;
+}
+
+// bin_averages (edge:1436-1449) of one chain's accumulators
+static void bin_averages(const EdgeScalars &s, int64_t bins, int n_rl, sac_edge_results_t &r)
+{
+    const double b = (double)bins, den = std::sqrt((double)(bins - 1));
+    for (int q = 0; q < 3; ++q) {
+        r.chi2_res[q] = s.chi2_res[q] / b;
+        for (int rl = 0; rl < 2; ++rl) {
+            r.edge_res[q][rl] = s.edge_res[q][rl] / b;
+            r.n0_res[q][rl] = s.n0_res[q][rl] / b;
+            r.wn0_res[q][rl] = s.wn0_res[q][rl] / b;
+        }
+    }
+    r.chi2_res[2] = std::sqrt(std::fabs(r.chi2_res[2] - r.chi2_res[1] * r.chi2_res[1])) / den;
+    for (int rl = 0; rl < n_rl; ++rl) {
+        r.n0_res[2][rl] = std::sqrt(std::fabs(r.n0_res[2][rl] - r.n0_res[1][rl] * r.n0_res[1][rl])) / den;
+        r.wn0_res[2][rl] = std::sqrt(std::fabs(r.wn0_res[2][rl] - r.wn0_res[1][rl] * r.wn0_res[1][rl])) / den;
+        r.edge_res[2][rl] = std::sqrt(std::fabs(r.edge_res[2][rl] - r.edge_res[1][rl] * r.edge_res[1][rl])) / den;
+    }
+}
+
+// chain = -1: mean over chains of every entry (chi2_min: minimum; counters, violations: sums)
+extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_results_t *out)
+{
+    if (!h || !out) return efail(SAC_E_INVALID, "sac_edge_get_results: null argument");
+    const int nc = h->cfg.n_chains;
+    if (chain < -1 || chain >= nc) return efail(SAC_E_INVALID, "sac_edge_get_results: chain %d outside -1..%d", chain, nc - 1);
+    if (h->last_bins < 2) return efail(SAC_E_STATE, "sac_edge_get_results: no run_bins stage has run");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
+    std::vector<EdgeScalars> sc((size_t)count);
+    HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof(*out));
+    out->chi2_min = 1e300;
+    for (const auto &s : sc) {
+        sac_edge_results_t r;
+        std::memset(&r, 0, sizeof(r));
+        bin_averages(s, h->last_bins, h->cfg.n_rl, r);
+        for (int q = 0; q < 3; ++q) {
+            out->chi2_res[q] += r.chi2_res[q] / count;
+            for (int rl = 0; rl < 2; ++rl) {
+                out->edge_res[q][rl] += r.edge_res[q][rl] / count;
+                out->n0_res[q][rl] += r.n0_res[q][rl] / count;
+                out->wn0_res[q][rl] += r.wn0_res[q][rl] / count;
+                out->amp_accept_rates[q][rl] += s.amp_ar[q][rl] / count;
+            }
+        }
+        for (int rl = 0; rl < 2; ++rl) {
+            out->n0[rl] += s.n0[rl] / count; out->eps0[rl] += s.eps0[rl] / count;
+            out->dn0[rl] += s.dn0[rl] / count; out->deps0[rl] += s.deps0[rl] / count;
+        }
+        out->chi2 += s.chi2 / count;
+        if (s.chi2_min < out->chi2_min) out->chi2_min = s.chi2_min;
+        out->sweeps = s.sweep;
+        out->proposals += s.counters[0]; out->evaluated += s.counters[1]; out->accepted += s.counters[2];
+        out->lookups += s.counters[4]; out->violations += s.violations;
+    }
+    out->last_stage_ms = h->last_stage_ms;
+    return SAC_OK;
+}
+
+// accept_rates[m, :, side] (edge:68) after the last adjust_D: N_w+1 doubles; chain = -1: chain mean
+extern "C" int sac_edge_get_accept_rates(sac_edge_t *h, int32_t chain, int32_t m, int32_t side, double *out)
+{
+    if (!h || !out) return efail(SAC_E_INVALID, "sac_edge_get_accept_rates: null argument");
+    const int nc = h->cfg.n_chains, n1 = h->cfg.n_omega + 1, S = h->S;
+    if (chain < -1 || chain >= nc || m < 0 || m > 1 || side < 0 || side > 1)
+        return efail(SAC_E_INVALID, "sac_edge_get_accept_rates: bad chain/m/side");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
+    std::vector<double> buf((size_t)count * 4 * S);
+    HIP_TRY(hipMemcpy(buf.data(), h->dArc + (size_t)first * 4 * S, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 1; k <= n1; ++k) out[k - 1] = 0.0;
+    for (int c = 0; c < count; ++c)
+        for (int k = 1; k <= n1; ++k) out[k - 1] += buf[(size_t)c * 4 * S + ((size_t)side * 2 + m) * S + k] / count;
+    return SAC_OK;
+}
+
+// sampled_spec[:, which, side] (edge:75): accumulated (not normalised) sums, averaged over chains
+extern "C" int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side, double *out)
+{
+    if (!h || !out) return efail(SAC_E_INVALID, "sac_edge_get_histogram: null argument");
+    if (which < 0 || which > 1 || side < 0 || side > 1) return efail(SAC_E_INVALID, "sac_edge_get_histogram: which/side");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t ng = (size_t)h->cfg.n_grid;
+    std::vector<double> tmp(ng);
+    for (size_t i = 0; i < ng; ++i) out[i] = 0.0;
+    for (int c = 0; c < h->hist_copies; ++c) {
+        HIP_TRY(hipMemcpy(tmp.data(), h->dHist + ((size_t)c * 4 + (size_t)side * 2 + which) * ng, ng * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ng; ++i) out[i] = out[i] + tmp[i];
+    }
+    const double nc = (double)h->cfg.n_chains;
+    if (nc > 1)
+        for (size_t i = 0; i < ng; ++i) out[i] = out[i] / nc;
+    return SAC_OK;
+}
+
+// w_avg / A_avg (edge:83-84) [N_w+1, 2], accumulated sums; chain = -1: chain mean
+extern "C" int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, double *A_avg)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_get_avg: null handle");
+    const int nc = h->cfg.n_chains, n1 = h->cfg.n_omega + 1, S = h->S;
+    if (chain < -1 || chain >= nc) return efail(SAC_E_INVALID, "sac_edge_get_avg: chain %d", chain);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
+    std::vector<double> buf((size_t)count * 2 * S);
+    for (int pass = 0; pass < 2; ++pass) {
+        double *dst = pass == 0 ? w_avg : A_avg;
+        if (!dst) continue;
+        HIP_TRY(hipMemcpy(buf.data(), (pass == 0 ? h->dWavg : h->dAavg) + (size_t)first * 2 * S, buf.size() * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        for (int i = 0; i < 2 * n1; ++i) dst[i] = 0.0;
+        for (int c = 0; c < count; ++c)
+            for (int rl = 0; rl < 2; ++rl)
+                for (int k = 1; k <= n1; ++k) dst[rl * n1 + k - 1] += buf[(size_t)c * 2 * S + (size_t)rl * S + k] / count;
+    }
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_get_gbar: null handle");
+    if (chain < 0 || chain >= h->cfg.n_chains) return efail(SAC_E_INVALID, "sac_edge_get_gbar: chain %d", chain);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (gbar)
+        HIP_TRY(hipMemcpy(gbar, h->dGbar + (size_t)chain * SAC_MAX_N_TAU, (size_t)h->cfg.n_tau * sizeof(double), hipMemcpyDeviceToHost));
+    EdgeScalars s;
+    HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    if (chi2) *chi2 = s.chi2;
+    if (chi2_min) *chi2_min = s.chi2_min;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_set_move_log(sac_edge_t *h, int32_t chain, int64_t capacity)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_set_move_log: null handle");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->dLog) { HIP_TRY(hipFree(h->dLog)); h->dLog = nullptr; }
+    h->log_chain = -1;
+    h->log_cap = 0;
+    if (chain < 0 || capacity <= 0) return SAC_OK;
+    if (chain >= h->cfg.n_chains) return efail(SAC_E_INVALID, "sac_edge_set_move_log: chain %d", chain);
+    HIP_TRY(hipMalloc((void **)&h->dLog, (size_t)capacity * sizeof(MoveRec)));
+    HIP_TRY(hipMemset(h->dLogLen, 0, sizeof(unsigned long long)));
+    h->log_chain = chain;
+    h->log_cap = capacity;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_move_log(sac_edge_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded)
+{
+    if (!h || !n_recorded) return efail(SAC_E_INVALID, "sac_edge_get_move_log: null argument");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    unsigned long long n = 0;
+    if (h->dLog) HIP_TRY(hipMemcpy(&n, h->dLogLen, sizeof(n), hipMemcpyDeviceToHost));
+    *n_recorded = (int64_t)n;
+    long long m = (long long)n < h->log_cap ? (long long)n : h->log_cap;
+    if (m > capacity) m = capacity;
+    if (out && m > 0) {
+        static_assert(sizeof(MoveRec) == sizeof(sac_move_rec_t), "move record layout");
+        HIP_TRY(hipMemcpy(out, h->dLog, (size_t)m * sizeof(MoveRec), hipMemcpyDeviceToHost));
+    }
+    return SAC_OK;
+}

@@ -514,6 +514,13 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// for the library's other translation units (sac_edge.hip): same thread-local message buffer
+int sac_internal_fail(int code, const char *msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \

@@ -15,6 +15,10 @@ EXPORTS = [
     "sac_get_histogram_sum_device", "sac_set_move_log", "sac_get_move_log",
     "sac_upload_problem_peak", "sac_sample_bin", "sac_set_indiv_update", "sac_zero_accumulators",
     "sac_get_peak_stats", "sac_get_histogram_peak", "sac_get_bounds", "sac_copy_chain", "sac_get_chain_chi2",
+    "sac_edge_create", "sac_edge_destroy", "sac_edge_upload_problem", "sac_edge_set_state", "sac_edge_get_state",
+    "sac_edge_init_gbar", "sac_edge_run_bins", "sac_edge_get_results", "sac_edge_get_accept_rates",
+    "sac_edge_get_histogram", "sac_edge_get_avg", "sac_edge_get_gbar", "sac_edge_set_move_log",
+    "sac_edge_get_move_log",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -55,6 +59,25 @@ class PeakStats(C.Structure):
                 ("last_kernel_launches", C.c_int64)]
 
 
+class EdgeConfig(C.Structure):
+    _fields_ = [("n_tau", C.c_int32), ("n_e", C.c_int32), ("n_omega", C.c_int32), ("n_rl", C.c_int32),
+                ("double_in", C.c_int32), ("fix_edge", C.c_int32), ("n_chains", C.c_int32), ("device", C.c_int32),
+                ("wi_0", C.c_int64), ("n_grid", C.c_int64), ("A_c", C.c_double), ("A_r", C.c_double),
+                ("d0", C.c_double), ("w_floor", C.c_double * 2), ("w_m", C.c_double), ("d_omega", C.c_double),
+                ("c", C.c_double * 2), ("seed", C.c_uint64), ("chain_offset", C.c_uint32),
+                ("sweeps_per_launch", C.c_int32), ("hist_copies", C.c_int32), ("reserved", C.c_int32)]
+
+
+class EdgeResults(C.Structure):
+    _fields_ = [("chi2_res", C.c_double * 3), ("edge_res", (C.c_double * 2) * 3), ("n0_res", (C.c_double * 2) * 3),
+                ("wn0_res", (C.c_double * 2) * 3), ("amp_accept_rates", (C.c_double * 2) * 3),
+                ("n0", C.c_double * 2), ("eps0", C.c_double * 2), ("dn0", C.c_double * 2), ("deps0", C.c_double * 2),
+                ("chi2", C.c_double), ("chi2_min", C.c_double),
+                ("sweeps", C.c_uint64), ("proposals", C.c_uint64), ("evaluated", C.c_uint64),
+                ("accepted", C.c_uint64), ("lookups", C.c_uint64), ("violations", C.c_uint64),
+                ("last_stage_ms", C.c_double)]
+
+
 MOVE_REC = np.dtype([("chi2_new", "<f8"), ("flags", "<i4"), ("move", "<i4")])
 
 
@@ -92,6 +115,23 @@ def load_library():
     L.sac_get_peak_stats.argtypes = [vp, C.POINTER(PeakStats)]
     L.sac_get_histogram_peak.argtypes = [vp, C.c_int32, dp]
     L.sac_get_bounds.argtypes = [vp, C.c_int32, dp]
+    L.sac_copy_chain.argtypes = [vp, C.c_int32, C.c_int32]
+    L.sac_get_chain_chi2.argtypes = [vp, dp, dp]
+    pdp = C.POINTER(dp)
+    L.sac_edge_create.argtypes = [C.POINTER(EdgeConfig), C.POINTER(vp)]
+    L.sac_edge_destroy.argtypes = [vp]
+    L.sac_edge_upload_problem.argtypes = [vp, pdp, pdp, pdp, dp, dp]
+    L.sac_edge_set_state.argtypes = [vp, C.c_int32, dp, dp, dp, ip, dp]
+    L.sac_edge_get_state.argtypes = [vp, C.c_int32, dp, dp, dp, ip, dp]
+    L.sac_edge_init_gbar.argtypes = [vp]
+    L.sac_edge_run_bins.argtypes = [vp, C.c_int64, C.c_int64, C.c_double]
+    L.sac_edge_get_results.argtypes = [vp, C.c_int32, C.POINTER(EdgeResults)]
+    L.sac_edge_get_accept_rates.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, dp]
+    L.sac_edge_get_histogram.argtypes = [vp, C.c_int32, C.c_int32, dp]
+    L.sac_edge_get_avg.argtypes = [vp, C.c_int32, dp, dp]
+    L.sac_edge_get_gbar.argtypes = [vp, C.c_int32, dp, dp, dp]
+    L.sac_edge_set_move_log.argtypes = [vp, C.c_int32, C.c_int64]
+    L.sac_edge_get_move_log.argtypes = [vp, vp, C.c_int64, ip]
     for name in EXPORTS:
         if name != "sac_last_error":
             getattr(L, name).restype = C.c_int
@@ -260,3 +300,121 @@ class SacHandle:
         n = C.c_int64()
         self._check(self.L.sac_get_move_log(self.h, out.ctypes.data, capacity, C.byref(n)))
         return out[:min(n.value, capacity)], n.value
+
+
+class SacEdgeHandle:
+    """ctypes view of one sac_edge_t (edge parameterisation).  State arrays are [N_w+1, 2] numpy arrays
+    (the reference's shape); they cross the ABI column-major (side after side)."""
+
+    def __init__(self, n_tau, n_e, n_omega, n_grid, wi_0, d_omega, w_m, w_floor, c, n_rl=1, double_in=0,
+                 fix_edge=0, A_c=0.0, A_r=1.0, d0=0.0, n_chains=1, seed=0, chain_offset=0, device=0,
+                 sweeps_per_launch=0, hist_copies=0):
+        self.L = load_library()
+        self.cfg = EdgeConfig(int(n_tau), int(n_e), int(n_omega), int(n_rl), int(double_in), int(fix_edge),
+                              int(n_chains), int(device), int(wi_0), int(n_grid), float(A_c), float(A_r), float(d0),
+                              (C.c_double * 2)(*[float(x) for x in w_floor]), float(w_m), float(d_omega),
+                              (C.c_double * 2)(float(c), float(c)), int(seed), int(chain_offset),
+                              int(sweeps_per_launch), int(hist_copies), 0)
+        self.n_tau, self.n_e, self.n_omega, self.n_grid, self.n_rl = int(n_tau), int(n_e), int(n_omega), int(n_grid), int(n_rl)
+        self.h = C.c_void_p()
+        self._check(self.L.sac_edge_create(C.byref(self.cfg), C.byref(self.h)))
+        self._keep = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SacError(f"libsac_hip error {rc}: {self.L.sac_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sac_edge_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_problem(self, tables, G, sigma_inv):
+        """tables: per side (K, dK, d2K), each [n_grid, n_tau] C-order (= Julia's [N_tau, N_wi] slices)."""
+        if len(tables) != self.n_rl:
+            raise SacError(f"{len(tables)} table sets for n_rl = {self.n_rl}")
+        keep = [[np.ascontiguousarray(t, dtype=np.float64) for t in side] for side in tables]
+        for side in keep:
+            for t in side:
+                if t.shape != (self.n_grid, self.n_tau):
+                    raise SacError(f"table has shape {t.shape}, expected {(self.n_grid, self.n_tau)}")
+        dp = C.POINTER(C.c_double)
+        arrs = [(dp * 2)(*([_dp(side[i]) for side in keep] + [None] * (2 - len(keep)))) for i in range(3)]
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        sigma_inv = np.ascontiguousarray(sigma_inv, dtype=np.float64)
+        self._check(self.L.sac_edge_upload_problem(self.h, arrs[0], arrs[1], arrs[2], _dp(G), _dp(sigma_inv)))
+
+    @staticmethod
+    def _cm(a, dtype=np.float64):
+        return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=dtype).T).ravel()
+
+    def set_state(self, w=None, A=None, dw=None, nm=None, scal=None, chain=-1):
+        n1 = self.n_omega + 1
+        for a in (w, A, dw, nm):
+            if a is not None and np.asarray(a).shape != (n1, 2):
+                raise SacError(f"state array has shape {np.asarray(a).shape}, expected {(n1, 2)}")
+        w, A, dw = self._cm(w), self._cm(A), self._cm(dw)
+        nm = self._cm(nm, np.int64)
+        scal = None if scal is None else np.ascontiguousarray(scal, dtype=np.float64)
+        self._check(self.L.sac_edge_set_state(self.h, chain, _dp(w), _dp(A), _dp(dw), _ip(nm), _dp(scal)))
+
+    def get_state(self, chain=0):
+        n1 = self.n_omega + 1
+        w, A, dw, scal = np.empty(2 * n1), np.empty(2 * n1), np.empty(2 * n1), np.empty(8)
+        nm = np.empty(2 * n1, dtype=np.int64)
+        self._check(self.L.sac_edge_get_state(self.h, chain, _dp(w), _dp(A), _dp(dw), _ip(nm), _dp(scal)))
+        r = lambda a: a.reshape(2, n1).T.copy()
+        return dict(w=r(w), A=r(A), dw=r(dw), nm=r(nm), scal=scal)
+
+    def init_gbar(self):
+        self._check(self.L.sac_edge_init_gbar(self.h))
+
+    def run_bins(self, steps, bins, theta):
+        self._check(self.L.sac_edge_run_bins(self.h, int(steps), int(bins), float(theta)))
+
+    def results(self, chain=-1):
+        r = EdgeResults()
+        self._check(self.L.sac_edge_get_results(self.h, chain, C.byref(r)))
+        f = lambda a: np.array([list(x) for x in a])
+        return dict(chi2_res=np.array(r.chi2_res[:]), edge_res=f(r.edge_res), n0_res=f(r.n0_res), wn0_res=f(r.wn0_res),
+                    amp_ar=f(r.amp_accept_rates), n0=np.array(r.n0[:]), eps0=np.array(r.eps0[:]),
+                    dn0=np.array(r.dn0[:]), deps0=np.array(r.deps0[:]), chi2=r.chi2, chi2_min=r.chi2_min,
+                    sweeps=r.sweeps, proposals=r.proposals, evaluated=r.evaluated, accepted=r.accepted,
+                    lookups=r.lookups, violations=r.violations, last_stage_ms=r.last_stage_ms)
+
+    def accept_rates(self, m, side, chain=-1):
+        a = np.empty(self.n_omega + 1)
+        self._check(self.L.sac_edge_get_accept_rates(self.h, chain, m, side, _dp(a)))
+        return a
+
+    def histogram(self, which, side):
+        o = np.empty(self.n_grid)
+        self._check(self.L.sac_edge_get_histogram(self.h, which, side, _dp(o)))
+        return o
+
+    def avg(self, chain=-1):
+        n1 = self.n_omega + 1
+        w, A = np.empty(2 * n1), np.empty(2 * n1)
+        self._check(self.L.sac_edge_get_avg(self.h, chain, _dp(w), _dp(A)))
+        return w.reshape(2, n1).T.copy(), A.reshape(2, n1).T.copy()
+
+    def get_gbar(self, chain=0):
+        g = np.empty(self.n_tau)
+        c, m = C.c_double(), C.c_double()
+        self._check(self.L.sac_edge_get_gbar(self.h, chain, _dp(g), C.byref(c), C.byref(m)))
+        return g, c.value, m.value
+
+    def set_move_log(self, chain, capacity):
+        self._check(self.L.sac_edge_set_move_log(self.h, chain, capacity))
+
+    def move_log(self, capacity):
+        out = np.zeros(capacity, dtype=MOVE_REC)
+        n = C.c_int64()
+        self._check(self.L.sac_edge_get_move_log(self.h, out.ctypes.data, capacity, C.byref(n)))
+        return out[: min(n.value, capacity)], n.value
