@@ -145,3 +145,22 @@ def test_sac_log_exp_accuracy():
     for x in np.concatenate([rng.uniform(-20.0, 5.0, 2000), rng.uniform(-0.4, 0.4, 500)]):
         ref = math.exp(x)
         assert abs(ora.sac_exp(x) - ref) <= 2 * np.spacing(ref)
+
+
+def test_oracle_follows_the_reference_run_statistically():
+    """t2_double_symm with the reference's own equilibration (5 x 600 sweeps x 20 bins at Theta = 10) and its
+    first anneal stage, on a 100x coarser kernel grid: the committed anneal.csv of the real Julia run says
+    chi2_min 0.861, <chi2> 2.73 +- 0.07, edge 0.649, n0/N_e 0.499 (rows j = 0, 1)."""
+    tin, tab, init, o = make_chain("t2_symm", 1e-3, 80, seed=5)
+    nt = tin["n_tau"]
+    ref = np.genfromtxt(f"{EDGE}/t2_symm/anneal.csv", delimiter=",", skip_header=1)
+    o.run_bins(3000, 20, 10.0)
+    r = o.results()
+    assert o.get_gbar()[2] / nt == pytest.approx(ref[0, 2], rel=0.1)          # chi2_min / N_tau
+    assert r["edge_res"][1, 0] == pytest.approx(ref[0, 5], abs=0.03)
+    o.run_bins(588, 20, 10.0)
+    r = o.results()
+    assert r["chi2_res"][1] / nt == pytest.approx(ref[1, 3], rel=0.15)        # <chi2> / N_tau
+    assert r["edge_res"][1, 0] == pytest.approx(ref[1, 5], abs=0.015)
+    assert r["n0_res"][1, 0] == pytest.approx(ref[1, 7], abs=0.05)
+    assert o.violations() == 0
