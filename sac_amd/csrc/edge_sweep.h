@@ -166,6 +166,22 @@ struct EdgeChain {
         n_cols += 1;
     }
 
+    // the three table reads of a lookup, arithmetic left to the caller (lets several lookups overlap)
+    __device__ __forceinline__ void taylor_fetch(int rl, double wk, double (&raw)[3][NTL], double &d, double &d2) const
+    {
+        const long long wi = (long long)__builtin_floor(wk / p->dwg);
+        d = wk - ((double)wi * p->dwg);
+        d2 = d * d;
+        long long col = wi - p->wi0;
+        col = col < 0 ? 0 : (col >= p->n_grid ? p->n_grid - 1 : col);
+        const char *b = reinterpret_cast<const char *>(p->tab[rl]) + (size_t)col * 3u * (size_t)p->ntp * 8u;
+        const size_t cb = (size_t)p->ntp * 8u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) raw[q][t] = *reinterpret_cast<const double *>(b + q * cb + off[t]);
+    }
+
     __device__ __forceinline__ double col_get(const double *base, int k, int t) const
     {
         return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (size_t)k * p->ntp * 8u + off[t]);
@@ -201,8 +217,10 @@ struct EdgeChain {
     }
 
     // edge:800-813 (first = 2), edge:907-918 (first = 1)
-    __device__ __forceinline__ void edge_bounds(int rl, int first)
+    template <int RL>
+    __device__ __forceinline__ void edge_bounds(int first)
     {
+        constexpr int rl = RL;
         if (p->double_in) {
             wb0[rl] = -arr_max(w[1 - rl], first, p->N + 1);
             wbf[rl] = -w[1 - rl][2];
@@ -217,8 +235,10 @@ struct EdgeChain {
     }
 
     // edge:721-784
-    __device__ __forceinline__ int check_order(int k, double wk, int rl) const
+    template <int RL>
+    __device__ __forceinline__ int check_order(int k, double wk) const
     {
+        constexpr int rl = RL;
         const double *x = w[rl];
         const int NE = p->NE;
         const double d0 = p->d0;
@@ -256,9 +276,10 @@ struct EdgeChain {
     }
 
     // one-delta proposal shared by single_edge_move and single_cont_move: evaluate, accept, commit
-    template <bool LOG>
-    __device__ __forceinline__ void try_single(int move, int k, double wk, int rl, double u_acc)
+    template <bool LOG, int RL>
+    __device__ __forceinline__ void try_single(int move, int k, double wk, double u_acc)
     {
+        constexpr int rl = RL;
         double kn[NTL], gn[NTL];
         taylor(rl, wk, kn);
         const double Ak = A[rl][k];
@@ -277,11 +298,12 @@ struct EdgeChain {
     }
 
     // edge:793-885
-    template <bool LOG>
-    __device__ void single_edge_move(int rl)
+    template <bool LOG, int RL>
+    __device__ __forceinline__ void single_edge_move()
     {
+        constexpr int rl = RL;
         if (p->A_c == 1) return;
-        edge_bounds(rl, 2);
+        edge_bounds<RL>(2);
         const int NE = p->NE, move = ED_SINGLE + rl;
         const int k_0 = (p->fix_edge == 1) ? 3 : 2;
         const double *x = w[rl];
@@ -297,10 +319,10 @@ struct EdgeChain {
                 if (k < NE + 1) { if (wk < x[k - 1] || wk > x[k + 1]) ok = false; }
                 else { if (wk < x[k - 1] || wk > p->w_m || wk > wbf[rl]) ok = false; }
             }
-            if (ok) ok = (check_order(k, wk, rl) == 1);
+            if (ok) ok = (check_order<RL>(k, wk) == 1);
             if (!ok) { rec<LOG>(move, false, false, 0.0); continue; }
             const u32x4 b1 = block((uint32_t)move, (uint32_t)i, 1);
-            try_single<LOG>(move, k, wk, rl, u01(b1.x, b1.y));
+            try_single<LOG, RL>(move, k, wk, u01(b1.x, b1.y));
         }
     }
 
@@ -323,8 +345,10 @@ struct EdgeChain {
     }
 
     // edge:973-999
-    __device__ __forceinline__ int multi_1(int n, int rl, uint32_t move, uint32_t iter)
+    template <int RL>
+    __device__ __forceinline__ int multi_1(int n, uint32_t move, uint32_t iter)
     {
+        constexpr int rl = RL;
         const double *x = w[rl];
         double *m = mw[rl];
         const double d1 = x[n + 2] - x[n + 1];
@@ -352,8 +376,10 @@ struct EdgeChain {
     }
 
     // edge:1005-1052
-    __device__ __forceinline__ int multi_k(int k, int n, int rl, uint32_t move, uint32_t iter)
+    template <int RL>
+    __device__ __forceinline__ int multi_k(int k, int n, uint32_t move, uint32_t iter)
     {
+        constexpr int rl = RL;
         const double *x = w[rl];
         double *m = mw[rl];
         __syncthreads();
@@ -393,13 +419,14 @@ struct EdgeChain {
     }
 
     // edge:889-968
-    template <bool LOG>
-    __device__ void multi_edge_move(int rl)
+    template <bool LOG, int RL>
+    __device__ __forceinline__ void multi_edge_move()
     {
+        constexpr int rl = RL;
         if (p->A_c == 1) return;
         const int NE = p->NE;
         if (NE < 4) return;
-        edge_bounds(rl, 1);
+        edge_bounds<RL>(1);
         const uint32_t move = (uint32_t)(ED_MULTI + rl);
         for (int i = 0; i <= NE - 1; ++i) {
             const u32x4 b0 = block(move, (uint32_t)i, 0);
@@ -407,24 +434,41 @@ struct EdgeChain {
             if (i % 4 == 0 && p->fix_edge == 0) {
                 k = 2;
                 n = nm[rl][2];
-                pass = multi_1(n, rl, move, (uint32_t)i);
+                pass = multi_1<RL>(n, move, (uint32_t)i);
             } else {
                 k = 3 + index_from_word(b0.x, (uint32_t)(NE - 3));
                 n = nm[rl][k];
-                pass = multi_k(k, n, rl, move, (uint32_t)i);
+                pass = multi_k<RL>(k, n, move, (uint32_t)i);
             }
             if (pass != 1) { rec<LOG>((int)move, false, false, 0.0); continue; }
             double gn[NTL];
 #pragma unroll
             for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
-            for (int j = 0; j < n; ++j) {
-                double kn[NTL];
-                taylor(rl, mw[rl][k + j], kn);
-                const double Ak = A[rl][k + j];
+            // the cluster's columns: fetched CH at a time (independent gathers in flight together),
+            // accumulated in index order (edge:938-940)
+            constexpr int CH = 4;
+            for (int j0 = 0; j0 < n; j0 += CH) {
+                double raw[CH][3][NTL], old[CH][NTL], dd[CH], dd2[CH];
 #pragma unroll
-                for (int t = 0; t < NTL; ++t) {
-                    gn[t] = gn[t] + Ak * (kn[t] - col_get(kcurr[rl], k + j, t));
-                    col_put(knew[rl], k + j, t, kn[t]);
+                for (int u = 0; u < CH; ++u) {
+                    const int j = (j0 + u < n) ? j0 + u : n - 1;
+                    taylor_fetch(rl, mw[rl][k + j], raw[u], dd[u], dd2[u]);
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) old[u][t] = col_get(kcurr[rl], k + j, t);
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    if (j0 + u < n) {
+                        const int j = j0 + u;
+                        const double Ak = A[rl][k + j];
+#pragma unroll
+                        for (int t = 0; t < NTL; ++t) {
+                            const double kn = (raw[u][0][t] + (raw[u][1][t] * dd[u])) + (raw[u][2][t] * dd2[u]);
+                            gn[t] = gn[t] + Ak * (kn - old[u][t]);
+                            col_put(knew[rl], k + j, t, kn);
+                        }
+                        n_cols += 1;
+                    }
                 }
             }
             const double chi2_new = chi2_of(gn);
@@ -447,8 +491,10 @@ struct EdgeChain {
     }
 
     // amplitude profile of the edge into tempA[2..NE+1], normalised to f1 (edge:1091-1110)
-    __device__ __forceinline__ void edge_profile(int rl, double n1, double eps_prod)
+    template <int RL>
+    __device__ __forceinline__ void edge_profile(double n1, double eps_prod)
     {
+        constexpr int rl = RL;
         const double c = p->c[rl];
         const int NE = p->NE;
         __syncthreads();
@@ -470,9 +516,10 @@ struct EdgeChain {
     }
 
     // edge:1057-1142
-    template <bool LOG>
-    __device__ void amplitude_edge_move(int rl)
+    template <bool LOG, int RL>
+    __device__ __forceinline__ void amplitude_edge_move()
     {
+        constexpr int rl = RL;
         if (p->A_c == 1) return;
         const int NE = p->NE, move = ED_AMP + rl;
         if (NE < 3) return;
@@ -484,7 +531,7 @@ struct EdgeChain {
         if (n1 < 5 || n1 > (NE - 5)) { rec<LOG>(move, false, false, 0.0); return; }
         e1 += deps0[rl] * (u01(b0.z, b0.w) - 0.5);
         if (e1 < 0 || e1 > 1) { rec<LOG>(move, false, false, 0.0); return; }
-        edge_profile(rl, n1, e1 * eps);
+        edge_profile<RL>(n1, e1 * eps);
         double gn[NTL], acc_[NTL];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) acc_[t] = 0.0;
@@ -514,7 +561,7 @@ struct EdgeChain {
 
     // edge:1146-1189
     template <bool LOG>
-    __device__ void single_cont_move()
+    __device__ __forceinline__ void single_cont_move()
     {
         const int NE = p->NE, N = p->N;
         if (NE == N || p->A_c == 0) return;
@@ -526,13 +573,13 @@ struct EdgeChain {
             const double wk = x[k] + (dwn[0][k] * (u01(b0.y, b0.z) - 0.5));
             if (wk < wc_min || wk > wc_max) { rec<LOG>(ED_CONT, false, false, 0.0); continue; }
             const u32x4 b1 = block(ED_CONT, (uint32_t)it, 1);
-            try_single<LOG>(ED_CONT, k, wk, 0, u01(b1.x, b1.y));
+            try_single<LOG, 0>(ED_CONT, k, wk, u01(b1.x, b1.y));
         }
     }
 
     // edge:1194-1252
     template <bool LOG>
-    __device__ void amplitude_cont_move()
+    __device__ __forceinline__ void amplitude_cont_move()
     {
         const int NE = p->NE, N = p->N;
         if (NE == N || p->A_c == 0) return;

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
     c.chain = chain;
     {
         double *d = reinterpret_cast<double *>(s_dyn);
-        for (int rl = 0; rl < 2; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
             c.w[rl] = d; d += S;
             c.A[rl] = d; d += S;
             c.dwn[rl] = d; d += S;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
         c.bins = ip;
     }
     const size_t cs = (size_t)chain * 2u * (size_t)S;
-    for (int rl = 0; rl < 2; ++rl) {
+    _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
         const size_t o = cs + (size_t)rl * S;
         for (int k = lane; k < S; k += 64) {
             c.w[rl][k] = p.w[o + k];
@@ -101,9 +101,9 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
     EdgeScalars *scp = p.sc + chain;
     c.chi2 = scp->chi2;
     c.chi2_min = scp->chi2_min;
-    for (int rl = 0; rl < 2; ++rl) {
+    _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
         c.n0[rl] = scp->n0[rl]; c.eps0[rl] = scp->eps0[rl]; c.dn0[rl] = scp->dn0[rl]; c.deps0[rl] = scp->deps0[rl];
-        for (int m = 0; m < 3; ++m) c.amp_ar[m][rl] = scp->amp_ar[m][rl];
+        _Pragma("unroll") for (int m = 0; m < 3; ++m) c.amp_ar[m][rl] = scp->amp_ar[m][rl];
         c.wb0[rl] = c.wbf[rl] = p.w_m;
     }
     double chi2_acc = scp->chi2_res[0];
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
 
     if (p.flags & EDGE_BIN_START) {                       // edge:1263-1270
         chi2_acc = 0.0;
-        for (int rl = 0; rl < 2; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
             edge_acc[rl] = 0.0; n0_acc[rl] = 0.0; wn0_acc[rl] = 0.0;
             for (int k = lane; k < S; k += 64) { c.arc[rl][0][k] = 0.0; c.arc[rl][1][k] = 0.0; }
         }
@@ -156,10 +156,13 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
     for (int s = 0; s < p.n_sweeps; ++s) {
         c.sweep_lo = (uint32_t)sweep;
         c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
-        for (int rl = 0; rl < p.n_rl; ++rl) {             // edge:1273-1281
-            c.template single_edge_move<LOG>(rl);
-            c.template multi_edge_move<LOG>(rl);
-            c.template amplitude_edge_move<LOG>(rl);
+        c.template single_edge_move<LOG, 0>();            // edge:1273-1281
+        c.template multi_edge_move<LOG, 0>();
+        c.template amplitude_edge_move<LOG, 0>();
+        if (p.n_rl == 2) {
+            c.template single_edge_move<LOG, 1>();
+            c.template multi_edge_move<LOG, 1>();
+            c.template amplitude_edge_move<LOG, 1>();
         }
         if (p.A_c > 0) {                                  // edge:1283-1287
             c.template single_cont_move<LOG>();
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
         }
         // measure (edge:1305-1333)
         chi2_acc += c.chi2;
-        for (int rl = 0; rl < p.n_rl; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) if (rl < p.n_rl) {
             n0_acc[rl] += c.n0[rl] / NE;
             int idx = (int)__builtin_floor(c.n0[rl]);
             idx = idx < 1 ? 1 : (idx > N + 1 ? N + 1 : idx);
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
             scp->chi2_res[1] += c1;
             scp->chi2_res[2] += c1 * c1;
         }
-        for (int rl = 0; rl < 2; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
             n0_acc[rl] /= steps; wn0_acc[rl] /= steps; edge_acc[rl] /= steps;
             if (lane == 0) {
                 scp->n0_res[1][rl] += n0_acc[rl];
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
             }
         }
         // check_w (edge:658-718), counted instead of exit()
-        for (int rl = 0; rl < p.n_rl; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) if (rl < p.n_rl) {
             const double *x = c.w[rl];
             bool bad = false;
             if (x[2] < p.w_floor[rl]) bad = true;
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
         }
         // adjust_D (edge:1384-1432)
         __syncthreads();
-        for (int rl = 0; rl < p.n_rl; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) if (rl < p.n_rl) {
             for (int k = 1 + lane; k <= N + 1; k += 64) {
                 c.arc[rl][0][k] /= steps;
                 c.arc[rl][1][k] /= steps;
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
     }
 
     // write back
-    for (int rl = 0; rl < 2; ++rl) {
+    _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
         const size_t o = cs + (size_t)rl * S;
         for (int k = lane; k < S; k += 64) {
             p.w[o + k] = c.w[rl][k];
@@ -297,9 +300,9 @@ __global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
     if (lane == 0) {
         scp->chi2 = c.chi2;
         scp->chi2_min = c.chi2_min;
-        for (int rl = 0; rl < 2; ++rl) {
+        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
             scp->n0[rl] = c.n0[rl]; scp->eps0[rl] = c.eps0[rl]; scp->dn0[rl] = c.dn0[rl]; scp->deps0[rl] = c.deps0[rl];
-            for (int m = 0; m < 3; ++m) scp->amp_ar[m][rl] = c.amp_ar[m][rl];
+            _Pragma("unroll") for (int m = 0; m < 3; ++m) scp->amp_ar[m][rl] = c.amp_ar[m][rl];
             scp->edge_res[0][rl] = edge_acc[rl];
             scp->n0_res[0][rl] = n0_acc[rl];
             scp->wn0_res[0][rl] = wn0_acc[rl];
