@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Secondary throughput measurements (not the headline bench.py line): the peak and edge parameterisations
+at BASELINE.json configs[3] / configs[2] shapes on one MI355X.  Prints one JSON line per workload.
+
+    python tools/bench_param.py [peak|edge|both] [--chains N]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sac_amd.synth import synthetic_timedata  # noqa: E402
+
+SEED = 777
+
+
+def bench_peak(chains, d_omega=1e-5, n_omega=1000, sweeps=100):
+    """sac/peak, bosonic (one axis), N_tau=64, 10^6+1-column table (512 MB, beyond L2 + Infinity Cache)."""
+    from sac_amd.peak import PeakProblem
+    td = synthetic_timedata(n_tau=64, seed=SEED)
+    prob = PeakProblem(td, n_omega, 1, 0.5, 10.0, d_omega, kernel_type="bosonic")
+    h = prob.make_handle(n_chains=chains, seed=SEED)
+    h.adjust_windows(100, 1.0)
+    h.sample(20, 1.0)
+    s0 = h.peak_stats()
+    t0 = time.perf_counter()
+    h.sample(sweeps, 1.0)
+    s1 = h.peak_stats()
+    dt = time.perf_counter() - t0
+    cols = s1.columns_gathered - s0.columns_gathered
+    kms, nl = s1.last_kernel_ms, s1.last_kernel_launches
+    return {"workload": f"sac/peak bosonic, N_tau=64, {n_omega}+1 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
+                        f"{chains} chains, Theta=1", "chain_sweeps_per_s": chains * sweeps / dt,
+            "proposals_per_s": (s1.proposals - s0.proposals) / dt, "accepted_moves_per_s": (s1.accepted_moves - s0.accepted_moves) / dt,
+            "kernel": "peak_stage_kernel<1,false,false>", "launches": nl, "avg_launch_ms": kms / max(nl, 1),
+            "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9, "hbm_peak_GBps": 8000.0,
+            "frac": cols * 64 * 8 / (kms / 1e3) / 1e9 / 8000.0, "wall_s": dt}
+
+
+def bench_edge(chains, d_omega=1e-5, n_e=80, steps=40, bins=4):
+    """sac/edge single_edge, N_tau=64, N_e=80, three 10^6+1-column tables interleaved (1.5 GB)."""
+    from sac_amd.edge import EdgeProblem
+    td = synthetic_timedata(n_tau=64, seed=SEED)
+    prob = EdgeProblem(td, "single_edge", "bosonic", n_e, 0, 0.5, 0.0, 1.0, 0.0, 10.0, d_omega)
+    h = prob.make_handle(n_chains=chains, seed=SEED)
+    h.run_bins(20, 2, 1.0)
+    r0 = h.results(-1)
+    t0 = time.perf_counter()
+    h.run_bins(steps, bins, 1.0)
+    r1 = h.results(-1)
+    dt = time.perf_counter() - t0
+    look = r1["lookups"] - r0["lookups"]
+    ms = r1["last_stage_ms"]
+    bytes_alg = look * 5 * 64 * 8            # 3 table columns + K_curr read + K_new write per lookup
+    return {"workload": f"sac/edge single_edge bosonic, N_tau=64, N_e={n_e}, 3 x {prob.kernel.n_grid}-column tables "
+                        f"({3 * prob.kernel.n_grid * 512 / 2**20:.0f} MiB), {chains} chains, Theta=1",
+            "chain_sweeps_per_s": chains * steps * bins / dt, "proposals_per_s": (r1["proposals"] - r0["proposals"]) / dt,
+            "lookups_per_s": look / dt, "accepted_per_s": (r1["accepted"] - r0["accepted"]) / dt,
+            "kernel": "edge_stage_kernel<1,false>", "stage_ms": ms, "algorithmic_GBps": bytes_alg / (ms / 1e3) / 1e9,
+            "hbm_peak_GBps": 8000.0, "frac": bytes_alg / (ms / 1e3) / 1e9 / 8000.0, "violations": r1["violations"], "wall_s": dt}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="both")
+    ap.add_argument("--chains", type=int, default=4096)
+    a = ap.parse_args()
+    if a.which in ("peak", "both"):
+        print(json.dumps(bench_peak(a.chains)), flush=True)
+    if a.which in ("edge", "both"):
+        print(json.dumps(bench_edge(a.chains)), flush=True)
