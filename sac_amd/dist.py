@@ -45,6 +45,39 @@ class Comm:
                                accept_rates=[float(x) / n for x in buf[1:7]],
                                windows=[float(x) / n for x in buf[7:11]], n_chains=int(n))
 
+    def merge_named(self, n_chains, means, mins=None, sums=None):
+        """Generic per-stage merge used by the peak and edge drivers: `means` are this rank's
+        chain-means (weighted by n_chains across ranks), `mins` take the minimum, `sums` are added.
+        Values are scalars or arrays; one all-reduce(sum) + one all-reduce(min).  Returns a dict."""
+        import numpy as np
+        mins, sums = mins or {}, sums or {}
+        parts, layout = [], []
+        for kind, d, wgt in (("mean", means, float(n_chains)), ("sum", sums, 1.0)):
+            for k, v in d.items():
+                a = np.asarray(v, dtype=np.float64)
+                layout.append((kind, k, a.shape, a.size))
+                parts.append(a.ravel() * wgt)
+        parts.append(np.array([float(n_chains)]))
+        buf = torch.from_numpy(np.concatenate(parts)).to(self.device)
+        dist.all_reduce(buf, group=self.group)
+        buf = buf.cpu().numpy()
+        n_tot = buf[-1]
+        out, pos = {}, 0
+        for kind, k, shape, size in layout:
+            a = buf[pos:pos + size].reshape(shape)
+            out[k] = a / n_tot if kind == "mean" else a
+            if shape == ():
+                out[k] = float(out[k])
+            pos += size
+        if mins:
+            keys = list(mins)
+            mn = torch.tensor([float(mins[k]) for k in keys], dtype=torch.float64, device=self.device)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+            for k, v in zip(keys, mn.cpu().numpy()):
+                out[k] = float(v)
+        out["n_chains"] = int(round(n_tot))
+        return out
+
     def sum_vector(self, v):
         """All-reduce(sum) of a small host vector (e.g. the chain-summed Gbar of the cross-validation dump)."""
         t = torch.as_tensor(v, dtype=torch.float64).to(self.device)

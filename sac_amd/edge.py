@@ -221,7 +221,9 @@ class EdgeSAC:
 
     def __init__(self, N_e, N_c, omega_0, omega_m, d_omega_h, d_omega, p, A_c, A_r, theta_0, f_anneal, N_anneal,
                  a_criterion, anneal_steps, sample_steps, bins, G_file, output_folder, fix_edge, kernel_type, mode,
-                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None):
+                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None):
+        self.comm = comm
+        self.is_root = comm is None or comm.rank == 0
         self.N_e, self.N_c = int(N_e), int(N_c)
         self.omega_0, self.omega_m, self.d_omega_h, self.d_omega = float(omega_0), float(omega_m), float(d_omega_h), float(d_omega)
         self.p, self.A_c, self.A_r = float(p), float(A_c), float(A_r)
@@ -290,11 +292,15 @@ class EdgeSAC:
         return os.path.join(self.output_folder, name)
 
     def write_log(self, message, mode="a"):                                 # edge:1850-1860
+        if not self.is_root:
+            return
         now = datetime.datetime.now().isoformat(timespec="milliseconds")
         with open(self._path("log.txt"), mode) as f:
             f.write(f"{now} - {message}\n")
 
     def init_outfiles(self):                                                # edge:305-334
+        if not self.is_root:
+            return
         head = ("j,theta,chi2_min,chi2_avg,chi2_sigma,edge_R,wn0_R,n0_R,eps_R,edge_R_sigma,wn0_R_sigma,n0_R_sigma,"
                 "edge_L,wn0_L,n0_L,eps_L,edge_L_sigma,wn0_L_sigma,n0_L_sigma,wc0,w_cf\n")
         for name in ("anneal.csv", "sample.csv"):
@@ -319,7 +325,8 @@ class EdgeSAC:
             self.write_log(f"Leftward Edge: [{jl_float(-pr.w[1, 1])}, {jl_float(-pr.w[pr.n_e, 1])}]")
         if self.h is not None:
             self.h.close()
-        self.h = pr.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device)
+        offset = 0 if self.comm is None else self.comm.rank * self.n_chains
+        self.h = pr.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device, chain_offset=offset)
         self.chi2_min = self.h.get_gbar(0)[2]                               # all chains start from the same configuration
         self.write_log("Initialization Finished.")
 
@@ -327,16 +334,38 @@ class EdgeSAC:
     def run_bins(self, steps, bins, theta):                                 # edge:1357
         self.h.run_bins(steps, bins, theta)
         self.res = self.h.results(-1)
+        if self.comm is not None:                                           # one all-reduce per stage
+            r = self.res
+            keys = ("chi2_res", "edge_res", "n0_res", "wn0_res", "amp_ar", "n0", "eps0", "dn0", "deps0", "chi2")
+            m = self.comm.merge_named(self.n_chains, {k: r[k] for k in keys}, mins={"chi2_min": r["chi2_min"]},
+                                      sums={"violations": r["violations"]})
+            self.res = dict(r, **m)
         self.chi2_min = self.res["chi2_min"]
         if self.res["violations"]:
-            with open(self._path("error.txt"), "w") as f:                   # the reference exit()s here (edge:668)
+            with open(self._path("error.txt"), "a") as f:                   # the reference exit()s here (edge:668)
                 f.write(f"{jl_float(theta)} ordering / bound violations in {self.res['violations']} chain-bins\n")
             raise RuntimeError("check_w: ordering or bound violation (see error.txt)")
 
     def _chain_states(self):
         return [self.h.get_state(c) for c in range(min(self.n_chains, 32))]
 
+    def _hist(self, which, rl):
+        h = self.h.histogram(which, rl)
+        if self.comm is None:
+            return h
+        tot = self.comm.sum_vector(np.concatenate([h * self.n_chains, [float(self.n_chains)]]))
+        return tot[:-1] / tot[-1]
+
+    def _avg(self):
+        w, A = self.h.avg(-1)
+        if self.comm is None:
+            return w, A
+        m = self.comm.merge_named(self.n_chains, {"w": w, "A": A})
+        return m["w"], m["A"]
+
     def write_res(self, j, theta):                                          # edge:1452-1510
+        if not self.is_root:
+            return
         r, NE, N, nt = self.res, self.N_e, self.prob.n_omega, self.td.n_tau
         states = self._chain_states()
         if self.A_c > 0:
@@ -373,7 +402,10 @@ class EdgeSAC:
         wi0, wim, dw, dwh, NE = k.wi0, k.wim, self.d_omega, self.d_omega_h, self.N_e
         ngrid = wim + 1 - wi0
         hist = np.zeros((ngrid + 2, 2))
-        spec_bin = np.stack([self.h.histogram(0, rl), self.h.histogram(1, rl)], axis=1) / total_steps
+        spec_bin = np.stack([self._hist(0, rl), self._hist(1, rl)], axis=1) / total_steps
+        w_avg, A_avg = self._avg()
+        if not self.is_root:
+            return
         spec_bin = spec_bin * (self.td.norm * np.pi)
         conv = int(math.ceil(dwh / dw))
         N_h = int(math.floor((wim - wi0) / conv))
@@ -400,7 +432,6 @@ class EdgeSAC:
                 f.write(f"{fl(w)},{fl(hist[i - 1, 0] + hist[i - 1, 1])},{fl(hist[i - 1, 0])},{fl(hist[i - 1, 1])}\n")
             f.write(f"{fl(dwh * (j2 + 1 - 0.5) + self.omega_0)},0,0,0\n")
         # spectral density on the self-generated grid of the averaged deltas (edge:1573-1635)
-        w_avg, A_avg = self.h.avg(-1)
         wb, Ab = w_avg[:, rl] / total_steps, A_avg[:, rl] / total_steps     # 0-based rows = Julia index - 1
         jj = NE - 1
         i2 = 0
@@ -490,6 +521,8 @@ class EdgeSAC:
         return theta_opt
 
     def _sample_row(self, j, theta, with_cont):
+        if not self.is_root:
+            return
         r, NE, nt = self.res, self.N_e, self.td.n_tau
         vals = [theta, self.chi2_min / nt, r["chi2_res"][1] / nt, r["chi2_res"][2] / nt,
                 r["edge_res"][1, 0], r["wn0_res"][1, 0], r["n0_res"][1, 0], r["eps0"][0],
@@ -531,9 +564,9 @@ class EdgeSAC:
 
     def run(self, in_file=None, theta_1=None, theta_2=None):                # edge:1882-2065
         os.makedirs(self.output_folder, exist_ok=True)
-        if in_file and os.path.exists(in_file):
+        if self.is_root and in_file and os.path.exists(in_file):
             shutil.copyfile(in_file, self._path("in_edge.in"))
-        if self.timedata is None and os.path.exists(self.G_file):
+        if self.is_root and self.timedata is None and os.path.exists(self.G_file):
             shutil.copyfile(self.G_file, self._path("t.in"))
         n_w = self.N_e + (self.N_c if self.A_c > 0 else 0)
         self.write_log(f"N_ω, N_e, A_r, A_c, p = {n_w}, {self.N_e}, {jl_float(self.A_r)}, {jl_float(self.A_c)},{jl_float(self.p)}", "w")

@@ -115,7 +115,9 @@ class PeakSAC:
 
     def __init__(self, N_omega, N_p, A_0, omega_m, d_omega, d_omega_h, theta_0, f_anneal, a_criterion,
                  N_anneal, anneal_steps, sample_steps, G_file, output_folder, fix_edge, symm, kernel_type,
-                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None):
+                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None):
+        self.comm = comm
+        self.is_root = comm is None or comm.rank == 0
         self.N_omega, self.N_p, self.A_0 = int(N_omega), int(N_p), float(A_0)
         self.omega_m, self.d_omega, self.d_omega_h = float(omega_m), float(d_omega), float(d_omega_h)
         self.theta_0, self.f_anneal, self.a_criterion = float(theta_0), float(f_anneal), float(a_criterion)
@@ -173,6 +175,8 @@ class PeakSAC:
 
     def init_outfiles(self):                                        # peak:310-343
         import os
+        if not self.is_root:
+            return
         os.makedirs(self.output_folder, exist_ok=True)
         with open(self.anneal_file, "w") as f:
             f.write("i,theta,chi2_min,chi2_avg,edge_p,edge_n,Ap_p,Ap_n,Ac_p,Ac_n\n")
@@ -186,6 +190,8 @@ class PeakSAC:
 
     def write_log(self, message, mode="a"):                         # peak:1430-1434
         import datetime
+        if not self.is_root:
+            return
         now = datetime.datetime.now().isoformat(timespec="milliseconds")
         with open(self.output_folder + "/log.txt", mode) as f:
             f.write(f"{now} - {message}\n")
@@ -200,7 +206,8 @@ class PeakSAC:
         self.prob = PeakProblem(td, self.N_omega, self.N_p, self.A_0, self.omega_m, self.d_omega,
                                 omega_0=self.omega_0, fix_edge=self.fix_edge, symm=self.symm,
                                 kernel_type=self.kernel_type)
-        self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device)
+        offset = 0 if self.comm is None else self.comm.rank * self.n_chains
+        self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device, chain_offset=offset)
         self.h.set_indiv_update(self.indiv_update)
         self._merge()
 
@@ -212,6 +219,13 @@ class PeakSAC:
         self.edge_res = np.array([list(r) for r in st.edge_res])
         self.bounds = np.array(st.bounds[:])
         self.weights = np.array(st.weights[:])
+        if self.comm is not None:                                   # one all-reduce per stage
+            m = self.comm.merge_named(self.n_chains, dict(sampled_chi2=self.sampled_chi2, accept_rates=self.accept_rates,
+                                                          update_windows=self.update_windows, edge_res=self.edge_res,
+                                                          bounds=self.bounds, weights=self.weights),
+                                      mins=dict(chi2_min=self.chi2_min))
+            for k in ("sampled_chi2", "chi2_min", "accept_rates", "update_windows", "edge_res", "bounds", "weights"):
+                setattr(self, k, m[k])
         return st
 
     def repair_chains(self):
@@ -255,6 +269,8 @@ class PeakSAC:
         """peak:1322-1333 / 1410-1421 (the final row rounds the windows to 4 digits and does not
         scale window 11 by d_omega, as the reference does)."""
         from .free import _jl_round, jl_float
+        if not self.is_root:
+            return
         ar, w, dw = self.accept_rates, self.update_windows, self.d_omega
         wd = 4 if final else 8
         vals = ([_jl_round(x, 4) for x in ar[[0, 1, 2, 7, 8, 9]]] + [_jl_round(x * dw, wd) for x in w[[0, 1, 7, 8]]] +
@@ -282,8 +298,9 @@ class PeakSAC:
                 on_stage(i, theta)
             edge_p, edge_n, A0_p, A0_n, Ac_p, Ac_n = self._edges_and_weights()
             vals = [theta, self.chi2_min / n_tau, self.sampled_chi2 / n_tau, edge_p, edge_n, A0_p, A0_n, Ac_p, Ac_n]
-            with open(self.anneal_file, "a") as f:                  # peak:1315-1319
-                f.write(",".join([jl_float(float(i))] + [jl_float(_jl_round(v, 8)) for v in vals]) + "\n")
+            if self.is_root:
+                with open(self.anneal_file, "a") as f:              # peak:1315-1319
+                    f.write(",".join([jl_float(float(i))] + [jl_float(_jl_round(v, 8)) for v in vals]) + "\n")
             self._accept_row(i, final=False)
             if wr:
                 self.write_spec(i)
@@ -319,8 +336,9 @@ class PeakSAC:
                 _jl_round(self.sampled_chi2 / n_tau, 4), _jl_round(e[1, 0], 4), _jl_round(-e[1, 1], 4),
                 _jl_round(e[2, 0], 4), _jl_round(e[2, 1], 4), _jl_round(A0_p, 4), _jl_round(A0_n, 4),
                 _jl_round(Ac_p, 4), _jl_round(Ac_n, 4)]
-        with open(self.sample_file, "a") as f:                      # peak:1400-1408
-            f.write(",".join(jl_float(v) for v in vals) + "\n")
+        if self.is_root:
+            with open(self.sample_file, "a") as f:                  # peak:1400-1408
+                f.write(",".join(jl_float(v) for v in vals) + "\n")
         self._accept_row(0, final=True)
         self.write_spec(0)
         self.write_log("Final Sampling at θ_opt Finished.")
@@ -331,6 +349,11 @@ class PeakSAC:
         p = self.prob
         div = getattr(self, "spec_divisor", 1.0) if self.h is not None else 1.0
         hists = [self.h.histogram_peak(w) / (div if self._binned() else 1.0) for w in range(4)]
+        if self.comm is not None:
+            m = self.comm.merge_named(self.n_chains, {str(w): hists[w] for w in range(4)})
+            hists = [m[str(w)] for w in range(4)]
+        if not self.is_root:
+            return None
         pspec = np.stack([hists[0], hists[2]], axis=1)
         cspec = np.stack([hists[1], hists[3]], axis=1)
         i = np.arange(0, p.wi_m + 1)
@@ -411,10 +434,11 @@ class PeakSAC:
         self.run_anneal(theta, False)
         self.write_log("Anneal Finished.")
         a_vals, theta_vals, theta_opt = self.optimal_theta()
-        with open(self.output_folder + "/a_vals.csv", "w") as f:    # peak:1551-1554
-            f.write("a,theta\n")
-            for a, t in zip(a_vals, theta_vals):
-                f.write(f"{jl_float(a)},{jl_float(t)}\n")
+        if self.is_root:
+            with open(self.output_folder + "/a_vals.csv", "w") as f:    # peak:1551-1554
+                f.write("a,theta\n")
+                for a, t in zip(a_vals, theta_vals):
+                    f.write(f"{jl_float(a)},{jl_float(t)}\n")
         self.h.set_state(windows=np.full(11, self.prob.window / 10))   # peak:1557
         self.write_log("Beginning Final Anneal.")
         self.final_anneal(theta_opt)

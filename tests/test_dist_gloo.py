@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,3 +75,33 @@ def test_shard_chains_partitions():
         assert spans[0][0] == 0 and sum(c for _, c in spans) == n
         for (f0, c0), (f1, _) in zip(spans, spans[1:]):
             assert f0 + c0 == f1
+
+
+def _named_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sac_amd.dist import Comm
+    rng = np.random.default_rng(100 + rank)
+    n = 3 + 2 * rank                                  # unequal shards: 3 and 5 chains
+    per_chain = rng.normal(size=(n, 3, 2))
+    m = Comm().merge_named(n, {"res": per_chain.mean(axis=0), "chi2": float(per_chain[:, 0, 0].mean())},
+                           mins={"chi2_min": float(per_chain.min())}, sums={"violations": rank + 1})
+    out[rank] = dict(m, per_chain=per_chain)
+    dist.destroy_process_group()
+
+
+def test_merge_named_two_ranks():
+    """Generic merge of the peak / edge drivers: chain-weighted means, minima and sums."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_named_worker, args=(2, port, out), nprocs=2, join=True)
+    allc = np.concatenate([out[0]["per_chain"], out[1]["per_chain"]])
+    for r in (out[0], out[1]):
+        assert r["n_chains"] == 8
+        np.testing.assert_allclose(r["res"], allc.mean(axis=0), rtol=1e-13, atol=1e-15)
+        assert r["chi2"] == pytest.approx(allc[:, 0, 0].mean(), rel=1e-13)
+        assert r["chi2_min"] == allc.min()
+        assert r["violations"] == 3

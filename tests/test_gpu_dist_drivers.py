@@ -1,0 +1,80 @@
+"""N>1 path of the peak and edge drivers on the GPU box: two processes (gloo for the merge; both use the one
+MI355X of the box), chains sharded by chain_offset = rank * n_chains.  Every rank must end a stage with the
+statistics of the single-process run over all chains (a chain's trajectory depends only on its global id)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _edge(comm, n_chains, folder):
+    from sac_amd.edge import EdgeSAC
+    s = EdgeSAC.from_infile(f"{GOLD}/edge/t2_symm/in_edge.in", n_chains=n_chains, seed=31, comm=comm)
+    s.G_file, s.output_folder, s.d_omega = f"{GOLD}/edge/t2_symm/t.in", folder, 1e-3
+    os.makedirs(folder, exist_ok=True)
+    s.write_log("start", "w")
+    s.init_outfiles()
+    s.initialize()
+    s.run_bins(12, 3, 5.0)
+    s.write_res(1, 5.0)
+    s.write_spec(1, 36, 0)
+    r = s.res
+    return {k: np.array(r[k]) for k in ("chi2_res", "edge_res", "n0_res", "wn0_res", "amp_ar", "eps0")} | {"chi2_min": r["chi2_min"]}
+
+
+def _peak(comm, n_chains, folder):
+    from sac_amd.peak import PeakSAC
+    from sac_amd.tin import read_tin
+    td = read_tin(f"{GOLD}/cv/t_001a.in")
+    s = PeakSAC(60, 2, 0.6, 6.0, 2e-3, 0.05, 5.0, 1.1, 0.5, 5, 20, 20, "", folder, 0, 0, "finiteT",
+                n_chains=n_chains, seed=32, timedata=td, comm=comm)
+    os.makedirs(folder, exist_ok=True)
+    s.init_outfiles()
+    s.initialize()
+    s.adjust_windows(20, 5.0)
+    s.sample(10, 5.0)
+    spec = s.write_spec(1)
+    out = dict(sampled_chi2=s.sampled_chi2, chi2_min=s.chi2_min, accept_rates=np.array(s.accept_rates),
+               windows=np.array(s.update_windows), weights=np.array(s.weights))
+    if spec is not None:
+        out["spec"] = spec[0]
+    return out
+
+
+def _worker(rank, world, port, base, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sac_amd.dist import Comm
+    comm = Comm()
+    out[("edge", rank)] = _edge(comm, 4, f"{base}/edge2")
+    out[("peak", rank)] = _peak(comm, 4, f"{base}/peak2")
+    dist.destroy_process_group()
+
+
+def test_two_rank_drivers_equal_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    e1 = _edge(None, 8, str(tmp_path / "edge1"))
+    p1 = _peak(None, 8, str(tmp_path / "peak1"))
+    for rank in (0, 1):
+        e2, p2 = out[("edge", rank)], out[("peak", rank)]
+        for k, v in e1.items():
+            np.testing.assert_allclose(e2[k], v, rtol=1e-11, atol=1e-13, err_msg=f"edge {k}")
+        for k, v in p1.items():
+            if k in p2:
+                np.testing.assert_allclose(p2[k], v, rtol=1e-11, atol=1e-13, err_msg=f"peak {k}")
+    # only rank 0 wrote files, in the single-process layout
+    a = open(tmp_path / "edge2" / "anneal.csv").read().split("\n")
+    b = open(tmp_path / "edge1" / "anneal.csv").read().split("\n")
+    assert len(a) == len(b) == 3 and a[0] == b[0]
+    assert os.path.exists(tmp_path / "edge2" / "sw001_1.dat") and os.path.exists(tmp_path / "peak2" / "sw001.csv")
