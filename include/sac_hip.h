@@ -175,6 +175,19 @@ int sac_copy_chain(sac_handle_t *h, int32_t src, int32_t dst);
 /* chi2 and chi2_min of every chain of the handle (n_chains doubles each; either may be NULL). */
 int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min);
 
+/* Parity / debug entry (no counterpart in the reference): evaluates an explicit proposal stream
+ * on one chain of the free parameterisation (par = 1 or 3) -- what the reference's move loops do once the
+ * indices, the new positions (in bounds) and the accept uniform are drawn (free:296-320, 354-380, 437-470).
+ * chi2_new[n] / accepted[n] may be NULL.  Accepted proposals are committed to the chain. */
+typedef struct {
+    int32_t move;        /* number of deltas moved: 1, 2 or 3 */
+    int32_t k[3];        /* 0-based delta indices (distinct) */
+    int64_t w_new[3];    /* new grid indices, same coordinates as sac_set_state */
+    double  u;           /* the accept draw rand() */
+} sac_proposal_t;
+int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sac_proposal_t *props, int64_t n,
+               double *chi2_new, int32_t *accepted);
+
 /* Debug/parity: record every proposal of one chain (up to capacity) during the following stages. */
 int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);
 int sac_get_move_log(sac_handle_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);

@@ -489,6 +489,75 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const P
     }
 }
 
+// Explicit proposal stream for one chain of the free parameterisation (parity / debug entry,
+// SURVEY 8b-7): every proposal names its move (1, 2 or 3 deltas), the delta indices, their new
+// positions and the accept uniform, in the order a foreign sampler drew them.  Evaluation is the
+// sweep kernels' (free:296-303, 354-363, 437-449: Gbar_new, chi2_new, Metropolis, commit).
+struct ReplayProp { int move; int k[3]; long long w_new[3]; double u; };
+
+template <int NTL>
+__global__ void __launch_bounds__(64) replay_kernel(const FreeParams p, int chain, const ReplayProp *props, long long n,
+                                                    double *chi2_out, int *acc_out)
+{
+    const int lane = lane_id();
+    uint32_t *wi = p.wi + (size_t)chain * (size_t)p.wi_stride;
+    const double *A = p.A + (size_t)chain * (size_t)p.wi_stride;
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+    const char *Kb = reinterpret_cast<const char *>(p.K);
+    const size_t col_bytes = (size_t)p.ntp * 8u;
+    uint32_t off[NTL];
+    double gbar[NTL], G[NTL], sinv[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        gbar[t] = gbar_g[j];
+        G[t] = p.G[j];
+        sinv[t] = p.sinv[j];
+    }
+    double chi2 = p.sc[chain].chi2, chi2_min = p.sc[chain].chi2_min;
+    for (long long i = 0; i < n; ++i) {
+        const ReplayProp pr = props[i];
+        double gn[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
+        for (int e = 0; e < pr.move; ++e) {
+            const double a = p.uniform_A ? p.A_uniform : A[pr.k[e]];
+            const size_t cn = (size_t)pr.w_new[e] * col_bytes, co = (size_t)wi[pr.k[e]] * col_bytes;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const double kn = *reinterpret_cast<const double *>(Kb + cn + off[t]);
+                const double ko = *reinterpret_cast<const double *>(Kb + co + off[t]);
+                gn[t] = gn[t] + a * (kn - ko);
+            }
+        }
+        double term = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const double d = (gn[t] - G[t]) * sinv[t];
+            term = (t == 0) ? d * d : term + d * d;
+        }
+        const double chi2_new = wave_sum_uniform(term);
+        const bool acc = metropolis(chi2, chi2_new, p.inv2theta, log_u01(pr.u));
+        if (acc) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+            if (lane == 0)
+                for (int e = 0; e < pr.move; ++e) wi[pr.k[e]] = (uint32_t)pr.w_new[e];
+            chi2 = chi2_new;
+            if (chi2_new < chi2_min) chi2_min = chi2_new;
+            __syncthreads();
+        }
+        if (lane == 0) { chi2_out[i] = chi2_new; acc_out[i] = acc ? 1 : 0; }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        if (j < p.n_tau) gbar_g[j] = gbar[t];
+    }
+    if (lane == 0) { p.sc[chain].chi2 = chi2; p.sc[chain].chi2_min = chi2_min; }
+}
+
 // chi^2 of a given Gbar (sac_set_gbar consistency helper is host side; this kernel sums replicas)
 __global__ void hist_sum_kernel(const double *hist, long long n_grid, int copies, double *dst)
 {
@@ -1375,6 +1444,60 @@ extern "C" int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6,
     if (accept_rates)
         for (int k = 0; k < 6; ++k) accept_rates[k] = (h->last_stage == 2) ? s.acc[k] / steps : s.acc[k];
     return SAC_OK;
+}
+
+extern "C" int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sac_proposal_t *props, int64_t n,
+                          double *chi2_new, int32_t *accepted)
+{
+    if (!h || (n > 0 && !props)) return fail(SAC_E_INVALID, "sac_replay: null argument");
+    if (h->peak || h->cfg.par == 2) return fail(SAC_E_INVALID, "sac_replay: free parameterisation with par = 1 or 3 only");
+    if (chain < 0 || chain >= h->cfg.n_chains) return fail(SAC_E_INVALID, "sac_replay: chain %d outside 0..%d", chain, h->cfg.n_chains - 1);
+    int rc;
+    if ((rc = stage_begin(h, "sac_replay", n, theta))) return rc;
+    static_assert(sizeof(ReplayProp) == sizeof(sac_proposal_t), "proposal layout");
+    std::vector<ReplayProp> rel((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const sac_proposal_t &q = props[i];
+        if (q.move < 1 || q.move > 3) return fail(SAC_E_INVALID, "sac_replay: proposal %lld: move %d", (long long)i, q.move);
+        rel[(size_t)i].move = q.move;
+        rel[(size_t)i].u = q.u;
+        for (int e = 0; e < 3; ++e) {
+            rel[(size_t)i].k[e] = 0;
+            rel[(size_t)i].w_new[e] = 0;
+            if (e >= q.move) continue;
+            if (q.k[e] < 0 || q.k[e] >= h->cfg.n_omega)
+                return fail(SAC_E_INVALID, "sac_replay: proposal %lld: delta index %d outside 0..%d", (long long)i, q.k[e], h->cfg.n_omega - 1);
+            if (q.w_new[e] < h->cfg.wi_0 || q.w_new[e] > h->cfg.wi_m)      // the reference `continue`s before evaluating these
+                return fail(SAC_E_INVALID, "sac_replay: proposal %lld: position %lld outside [%lld, %lld]", (long long)i,
+                            (long long)q.w_new[e], (long long)h->cfg.wi_0, (long long)h->cfg.wi_m);
+            rel[(size_t)i].k[e] = q.k[e];
+            rel[(size_t)i].w_new[e] = q.w_new[e] - h->pos_offset;
+        }
+        for (int e = 1; e < q.move; ++e)
+            for (int f = 0; f < e; ++f)
+                if (q.k[e] == q.k[f]) return fail(SAC_E_INVALID, "sac_replay: proposal %lld repeats delta %d", (long long)i, q.k[e]);
+    }
+    if (n == 0) return stage_end(h, 0, 0);
+    ReplayProp *dP = nullptr;
+    double *dC = nullptr;
+    int *dAcc = nullptr;
+    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * sizeof(ReplayProp)));
+    HIP_TRY(hipMalloc((void **)&dC, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dAcc, (size_t)n * sizeof(int)));
+    HIP_TRY(hipMemcpy(dP, rel.data(), (size_t)n * sizeof(ReplayProp), hipMemcpyHostToDevice));
+    FreeParams p;
+    fill_params(h, p);
+    p.inv2theta = 1.0 / (2.0 * theta);
+    if (h->cfg.n_tau <= 64) hipLaunchKernelGGL(replay_kernel<1>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dC, dAcc);
+    else hipLaunchKernelGGL(replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dC, dAcc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dP));
+    HIP_TRY(hipFree(dC));
+    HIP_TRY(hipFree(dAcc));
+    return stage_end(h, 0, 0);
 }
 
 extern "C" int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min)

@@ -14,7 +14,7 @@ EXPORTS = [
     "sac_sample", "sac_get_stats", "sac_get_chain_stats", "sac_get_histogram",
     "sac_get_histogram_sum_device", "sac_set_move_log", "sac_get_move_log",
     "sac_upload_problem_peak", "sac_sample_bin", "sac_set_indiv_update", "sac_zero_accumulators",
-    "sac_get_peak_stats", "sac_get_histogram_peak", "sac_get_bounds", "sac_copy_chain", "sac_get_chain_chi2",
+    "sac_get_peak_stats", "sac_get_histogram_peak", "sac_get_bounds", "sac_copy_chain", "sac_get_chain_chi2", "sac_replay",
     "sac_edge_create", "sac_edge_destroy", "sac_edge_upload_problem", "sac_edge_set_state", "sac_edge_get_state",
     "sac_edge_init_gbar", "sac_edge_run_bins", "sac_edge_get_results", "sac_edge_get_accept_rates",
     "sac_edge_get_histogram", "sac_edge_get_avg", "sac_edge_get_gbar", "sac_edge_set_move_log",
@@ -78,6 +78,8 @@ class EdgeResults(C.Structure):
                 ("last_stage_ms", C.c_double)]
 
 
+PROPOSAL = np.dtype([("move", "<i4"), ("k", "<i4", 3), ("w_new", "<i8", 3), ("u", "<f8")])
+
 MOVE_REC = np.dtype([("chi2_new", "<f8"), ("flags", "<i4"), ("move", "<i4")])
 
 
@@ -116,6 +118,7 @@ def load_library():
     L.sac_get_histogram_peak.argtypes = [vp, C.c_int32, dp]
     L.sac_get_bounds.argtypes = [vp, C.c_int32, dp]
     L.sac_copy_chain.argtypes = [vp, C.c_int32, C.c_int32]
+    L.sac_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_get_chain_chi2.argtypes = [vp, dp, dp]
     pdp = C.POINTER(dp)
     L.sac_edge_create.argtypes = [C.POINTER(EdgeConfig), C.POINTER(vp)]
@@ -268,6 +271,14 @@ class SacHandle:
         out = np.empty(self.n_grid)
         self._check(self.L.sac_get_histogram_peak(self.h, int(which), _dp(out)))
         return out
+
+    def replay(self, props, theta, chain=0):
+        """props: array of PROPOSAL records.  Returns (chi2_new[n], accepted[n])."""
+        props = np.ascontiguousarray(props, dtype=PROPOSAL)
+        n = len(props)
+        c2, acc = np.empty(n), np.empty(n, dtype=np.int32)
+        self._check(self.L.sac_replay(self.h, chain, float(theta), props.ctypes.data, n, _dp(c2), acc.ctypes.data))
+        return c2, acc
 
     def chain_chi2(self):
         a, b = np.empty(self.cfg.n_chains), np.empty(self.cfg.n_chains)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from tests import helpers
-from sac_amd.lib import HIST_ACCUMULATE
+from sac_amd.lib import HIST_ACCUMULATE, SacError
 
 pytestmark = pytest.mark.gpu
 
@@ -186,4 +186,52 @@ def test_error_paths_do_not_exit():
         h.sample(10, 1.0)
     with pytest.raises(sac_amd.SacError, match="outside"):
         h.set_state(wi=np.full(50, 500, dtype=np.int64))
+    h.close()
+
+
+def test_replay_of_an_explicit_proposal_stream():
+    """sac_replay: a foreign proposal stream (indices, new positions, accept draws) evaluated by
+    the library agrees with a direct fp64 evaluation to <= 1e-12 relative per move (the north-star tolerance),
+    takes the same accept decisions and leaves a consistent chain behind."""
+    from sac_amd.lib import PROPOSAL
+    prob = helpers.problem_synth(n_tau=64, n_omega=200, omega_m=6.0, d_omega=1e-3)
+    h = prob.make_handle(n_chains=3, seed=5)
+    h.adjust_windows(20, 2.0)
+    chain, theta = 1, 2.0
+    wi, A, _ = h.get_state(chain)
+    gbar, chi2, _ = h.get_gbar(chain)
+    rng = np.random.default_rng(11)
+    n = 400
+    props = np.zeros(n, dtype=PROPOSAL)
+    wi_sim, g_sim, chi2_sim = wi.copy(), gbar.copy(), chi2
+    G, sinv, K = prob.td.G, prob.td.sigma_inv, prob.K
+    exp_chi2, exp_acc = np.empty(n), np.empty(n, dtype=np.int32)
+    for i in range(n):
+        m = int(rng.integers(1, 4))
+        ks = rng.choice(prob.n_omega, size=m, replace=False)
+        new = np.clip(wi_sim[ks] + rng.integers(-300, 301, size=m), prob.wi_0, prob.wi_m)
+        props[i]["move"], props[i]["u"] = m, rng.random()
+        props[i]["k"][:m], props[i]["w_new"][:m] = ks, new
+        gn = g_sim.copy()
+        for e in range(m):
+            gn = gn + A[ks[e]] * (K[new[e] - prob.wi_0] - K[wi_sim[ks[e]] - prob.wi_0])
+        c2 = float((((gn - G) * sinv) ** 2).sum())
+        acc = props[i]["u"] <= np.exp(min((chi2_sim - c2) / (2 * theta), 50.0))
+        exp_chi2[i], exp_acc[i] = c2, acc
+        if acc:
+            wi_sim[ks], g_sim, chi2_sim = new, gn, c2
+    c2_gpu, acc_gpu = h.replay(props, theta, chain=chain)
+    np.testing.assert_allclose(c2_gpu, exp_chi2, rtol=1e-12)
+    assert np.array_equal(acc_gpu, exp_acc) and 0 < acc_gpu.sum() < n
+    wi_g, _, _ = h.get_state(chain)
+    assert np.array_equal(wi_g, wi_sim)
+    g_g, chi2_g, _ = h.get_gbar(chain)
+    np.testing.assert_allclose(g_g, g_sim, rtol=1e-11, atol=1e-15)
+    assert chi2_g == pytest.approx(chi2_sim, rel=1e-12)
+    # the neighbouring chains are untouched; bad proposals are refused, not evaluated
+    bad = props[:1].copy()
+    bad[0]["w_new"][0] = prob.wi_m + 5
+    with pytest.raises(SacError):
+        h.replay(bad, theta, chain=chain)
+    h.sample(5, theta)                       # the chain keeps running from the replayed state
     h.close()

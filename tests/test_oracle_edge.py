@@ -46,7 +46,7 @@ def logged(name):
     return right, left
 
 
-@pytest.mark.parametrize("name", ["hchain_single", "t1_single", "t2_symm", "t3_in", "t4_out"])
+@pytest.mark.parametrize("name", ["hchain_single", "t1_single", "t2_symm", "t3_in", "t4_out", "tj_in_05", "tj_in_07"])
 def test_initial_scan_matches_reference_log(name):
     tin, tab, init = load_run(name)
     j_opt, k_opt, chi2 = init.config_dual()

@@ -12,6 +12,8 @@ RUNS = {
     "t2_symm": "t2_double_symm/Nw80/Ac_0.000/p_0.500",
     "t3_in": "t3_double_in/Nw80/Ac_0.000/p_0.500/Ar_0.500",
     "t4_out": "t4_double_out/Nw80/Ac_0.000/p_0.500/Ar_0.700",
+    "tj_in_05": "1D_tJ/04_pi2_double_in/Nw80/Ac_0.000/p_0.500/Ar_0.500",
+    "tj_in_07": "1D_tJ/04_pi2_double_in/Nw80/Ac_0.000/p_0.500/Ar_0.700",
 }
 
 
