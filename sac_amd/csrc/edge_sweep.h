@@ -277,7 +277,7 @@ struct EdgeChain {
 
     // one-delta proposal shared by single_edge_move and single_cont_move: evaluate, accept, commit
     template <bool LOG, int RL>
-    __device__ __forceinline__ void try_single(int move, int k, double wk, double u_acc)
+    __device__ __forceinline__ void try_single(int move, int k, double wk, double ln_u)
     {
         constexpr int rl = RL;
         double kn[NTL], gn[NTL];
@@ -286,7 +286,7 @@ struct EdgeChain {
 #pragma unroll
         for (int t = 0; t < NTL; ++t) gn[t] = gbar[t] + Ak * (kn[t] - col_get(kcurr[rl], k, t));
         const double chi2_new = chi2_of(gn);
-        const bool acc = accept_lt(chi2_new, u_acc);
+        const bool acc = ln_u < (chi2 - chi2_new) * inv2theta;
         if (acc) {
 #pragma unroll
             for (int t = 0; t < NTL; ++t) { gbar[t] = gn[t]; col_put(kcurr[rl], k, t, kn[t]); }
@@ -307,22 +307,30 @@ struct EdgeChain {
         const int NE = p->NE, move = ED_SINGLE + rl;
         const int k_0 = (p->fix_edge == 1) ? 3 : 2;
         const double *x = w[rl];
-        for (int i = 1; i <= NE; ++i) {
-            const u32x4 b0 = block((uint32_t)move, (uint32_t)i, 0);
-            int k;
-            if (i % 4 == 0 && p->fix_edge == 0) k = 2;
-            else k = k_0 + index_from_word(b0.x, (uint32_t)(NE + 2 - k_0));
-            const double wk = x[k] + (dwn[rl][k] * (u01(b0.y, b0.z) - 0.5));
-            bool ok = true;
-            if (k == 2 && wk > wb0[rl]) ok = false;
-            if (ok) {
-                if (k < NE + 1) { if (wk < x[k - 1] || wk > x[k + 1]) ok = false; }
-                else { if (wk < x[k - 1] || wk > p->w_m || wk > wbf[rl]) ok = false; }
+        // draws of 64 iterations at a time, one iteration per lane (Philox blocks 0 and 1, U - 1/2, ln U);
+        // the sequential loop below reads them with v_readlane
+        for (int base = 1; base <= NE; base += 64) {
+            const int cnt = (NE - base + 1 < 64) ? (NE - base + 1) : 64;
+            const u32x4 b0 = block((uint32_t)move, (uint32_t)(base + lane), 0);
+            const u32x4 b1 = block((uint32_t)move, (uint32_t)(base + lane), 1);
+            const int kk = k_0 + index_from_word(b0.x, (uint32_t)(NE + 2 - k_0));
+            const double ush = u01(b0.y, b0.z) - 0.5;
+            const double lnu = log_u01(u01(b1.x, b1.y));
+            for (int j = 0; j < cnt; ++j) {
+                const int i = base + j;
+                int k = __builtin_amdgcn_readlane(kk, j);
+                if (i % 4 == 0 && p->fix_edge == 0) k = 2;
+                const double wk = x[k] + (dwn[rl][k] * readlane_f64(ush, j));
+                bool ok = true;
+                if (k == 2 && wk > wb0[rl]) ok = false;
+                if (ok) {
+                    if (k < NE + 1) { if (wk < x[k - 1] || wk > x[k + 1]) ok = false; }
+                    else { if (wk < x[k - 1] || wk > p->w_m || wk > wbf[rl]) ok = false; }
+                }
+                if (ok) ok = (check_order<RL>(k, wk) == 1);
+                if (!ok) { rec<LOG>(move, false, false, 0.0); continue; }
+                try_single<LOG, RL>(move, k, wk, readlane_f64(lnu, j));
             }
-            if (ok) ok = (check_order<RL>(k, wk) == 1);
-            if (!ok) { rec<LOG>(move, false, false, 0.0); continue; }
-            const u32x4 b1 = block((uint32_t)move, (uint32_t)i, 1);
-            try_single<LOG, RL>(move, k, wk, u01(b1.x, b1.y));
         }
     }
 
@@ -388,10 +396,18 @@ struct EdgeChain {
         const double dk_minus1 = x[k] - x[k - 1];
         const double dk_plusn = x[k + n + 1] - x[k + n];
         uint32_t retry = 0;
-        for (int q = 0; q < n / 2; ++q) {
-            const u32x4 b = block(move, iter, (uint32_t)(1 + q));
-            const int i = index_from_word(b.x, (uint32_t)n);
-            int j = index_from_word(b.y, (uint32_t)n);
+        const int npair = n / 2;
+        const u32x4 pb0 = block(move, iter, (uint32_t)(1 + lane));          // pair q = lane
+        u32x4 pb1 = pb0;
+        if (npair > 64) pb1 = block(move, iter, (uint32_t)(65 + lane));     // pair q = 64 + lane
+        const double pu0 = u01(pb0.z, pb0.w), pu1 = u01(pb1.z, pb1.w);
+        for (int q = 0; q < npair; ++q) {
+            const int ql = q & 63;
+            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)((q < 64) ? pb0.x : pb1.x), ql);
+            const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)((q < 64) ? pb0.y : pb1.y), ql);
+            const double U = readlane_f64((q < 64) ? pu0 : pu1, ql);
+            const int i = index_from_word(wx, (uint32_t)n);
+            int j = index_from_word(wy, (uint32_t)n);
             while (j == i) {
                 if (retry > 255) return 0;
                 const u32x4 rb = block(move + (ED_MULTI_RETRY - ED_MULTI), iter, retry++);
@@ -401,7 +417,7 @@ struct EdgeChain {
             const double a = di + dj - dk_plusn, bb = di + dj - dk_minus1;
             const double d_min = (dk_minus1 > a) ? dk_minus1 : a;
             const double d_max = (dk_plusn < bb) ? dk_plusn : bb;
-            const double ni = d_min + (d_max - d_min) * u01(b.z, b.w);
+            const double ni = d_min + (d_max - d_min) * U;
             const double nj = di + dj - ni;
             __syncthreads();
             if (lane == 0) { tmpd[i] = ni; tmpd[j] = nj; }
@@ -428,15 +444,20 @@ struct EdgeChain {
         if (NE < 4) return;
         edge_bounds<RL>(1);
         const uint32_t move = (uint32_t)(ED_MULTI + rl);
-        for (int i = 0; i <= NE - 1; ++i) {
-            const u32x4 b0 = block(move, (uint32_t)i, 0);
+        for (int base = 0; base <= NE - 1; base += 64) {
+          const int cnt = (NE - base < 64) ? (NE - base) : 64;
+          const u32x4 b0 = block(move, (uint32_t)(base + lane), 0);      // one iteration per lane
+          const int kk = 3 + index_from_word(b0.x, (uint32_t)(NE - 3));
+          const double lnu = log_u01(u01(b0.y, b0.z));
+          for (int jj = 0; jj < cnt; ++jj) {
+            const int i = base + jj;
             int k, n, pass;
             if (i % 4 == 0 && p->fix_edge == 0) {
                 k = 2;
                 n = nm[rl][2];
                 pass = multi_1<RL>(n, move, (uint32_t)i);
             } else {
-                k = 3 + index_from_word(b0.x, (uint32_t)(NE - 3));
+                k = __builtin_amdgcn_readlane(kk, jj);
                 n = nm[rl][k];
                 pass = multi_k<RL>(k, n, move, (uint32_t)i);
             }
@@ -472,7 +493,7 @@ struct EdgeChain {
                 }
             }
             const double chi2_new = chi2_of(gn);
-            const bool acc = accept_lt(chi2_new, u01(b0.y, b0.z));
+            const bool acc = readlane_f64(lnu, jj) < (chi2 - chi2_new) * inv2theta;
             if (acc) {
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
@@ -487,6 +508,7 @@ struct EdgeChain {
                 __syncthreads();
             }
             rec<LOG>((int)move, true, acc, chi2_new);
+          }
         }
     }
 
@@ -567,13 +589,19 @@ struct EdgeChain {
         if (NE == N || p->A_c == 0) return;
         const double *x = w[0];
         const double wc_min = x[2], wc_max = x[NE + 1];
-        for (int it = 0; it < N - NE; ++it) {
-            const u32x4 b0 = block(ED_CONT, (uint32_t)it, 0);
-            const int k = NE + 2 + index_from_word(b0.x, (uint32_t)(N - NE));
-            const double wk = x[k] + (dwn[0][k] * (u01(b0.y, b0.z) - 0.5));
-            if (wk < wc_min || wk > wc_max) { rec<LOG>(ED_CONT, false, false, 0.0); continue; }
-            const u32x4 b1 = block(ED_CONT, (uint32_t)it, 1);
-            try_single<LOG, 0>(ED_CONT, k, wk, u01(b1.x, b1.y));
+        for (int base = 0; base < N - NE; base += 64) {
+            const int cnt = (N - NE - base < 64) ? (N - NE - base) : 64;
+            const u32x4 b0 = block(ED_CONT, (uint32_t)(base + lane), 0);
+            const u32x4 b1 = block(ED_CONT, (uint32_t)(base + lane), 1);
+            const int kk = NE + 2 + index_from_word(b0.x, (uint32_t)(N - NE));
+            const double ush = u01(b0.y, b0.z) - 0.5;
+            const double lnu = log_u01(u01(b1.x, b1.y));
+            for (int j = 0; j < cnt; ++j) {
+                const int k = __builtin_amdgcn_readlane(kk, j);
+                const double wk = x[k] + (dwn[0][k] * readlane_f64(ush, j));
+                if (wk < wc_min || wk > wc_max) { rec<LOG>(ED_CONT, false, false, 0.0); continue; }
+                try_single<LOG, 0>(ED_CONT, k, wk, readlane_f64(lnu, j));
+            }
         }
     }
 

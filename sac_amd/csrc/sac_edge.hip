@@ -45,8 +45,11 @@ constexpr size_t edge_lds_bytes(int S) { return (size_t)S * (15u * 8u + 3u * 4u)
 // One launch = n_sweeps sweeps of run_updates (edge:1260-1302) for every chain; by flag the
 // start-of-bin work (zero the bin accumulators and accept counters, Gbar = K_curr A) and the
 // end-of-bin work (record_bin, check_w, adjust_D).  One wave = one chain.
+#ifndef EDGE_WAVES
+#define EDGE_WAVES 2
+#endif
 template <int NTL, bool LOG>
-__global__ void __launch_bounds__(64) edge_stage_kernel(const EdgeParams p)
+__global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgeParams p)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const int chain = (int)blockIdx.x;
