@@ -44,7 +44,7 @@ struct EdgeParams {
     int log_chain;
     int n_chains, n_tau, ntp, NE, N, S, n_rl, double_in, fix_edge, hist_copies, hist_exclusive;
     long long n_grid, wi0;
-    double A_c, A_r, d0, w_floor[2], w_m, dwg, c[2];
+    double A_c, A_r, d0, w_floor[2], w_m, dwg, inv_dwg, c[2];
     uint32_t seed_lo, seed_hi, chain_offset;
     int n_sweeps, flags;
     double steps_in_bin, inv2theta;
@@ -146,13 +146,25 @@ struct EdgeChain {
         return wave_sum_uniform(term);
     }
 
+    // floor(w / dw) with the value the correctly rounded fp64 division gives (edge:626), |result| < 2^31.
+    // The reciprocal product decides unless it lies within a few ulp of an integer; then the division does.
+    __device__ __forceinline__ int grid_index(double wk) const
+    {
+        const double q = wk * p->inv_dwg;
+        const double f = __builtin_floor(q);
+        const double r = q - f;
+        const double m = __builtin_fabs(q) * 1e-15 + 1e-300;
+        if (r > m && r < 1.0 - m) return (int)f;
+        return (int)__builtin_floor(wk / p->dwg);
+    }
+
     // K(w) by the reference's lookup (edge:626-633): this lane's tau element(s)
     __device__ __forceinline__ void taylor(int rl, double wk, double (&out)[NTL])
     {
-        const long long wi = (long long)__builtin_floor(wk / p->dwg);
+        const int wi = grid_index(wk);
         const double d = wk - ((double)wi * p->dwg);
         const double d2 = d * d;
-        long long col = wi - p->wi0;
+        long long col = (long long)wi - p->wi0;
         col = col < 0 ? 0 : (col >= p->n_grid ? p->n_grid - 1 : col);
         const char *b = reinterpret_cast<const char *>(p->tab[rl]) + (size_t)col * 3u * (size_t)p->ntp * 8u;
         const size_t cb = (size_t)p->ntp * 8u;
@@ -169,10 +181,10 @@ struct EdgeChain {
     // the three table reads of a lookup, arithmetic left to the caller (lets several lookups overlap)
     __device__ __forceinline__ void taylor_fetch(int rl, double wk, double (&raw)[3][NTL], double &d, double &d2) const
     {
-        const long long wi = (long long)__builtin_floor(wk / p->dwg);
+        const int wi = grid_index(wk);
         d = wk - ((double)wi * p->dwg);
         d2 = d * d;
-        long long col = wi - p->wi0;
+        long long col = (long long)wi - p->wi0;
         col = col < 0 ? 0 : (col >= p->n_grid ? p->n_grid - 1 : col);
         const char *b = reinterpret_cast<const char *>(p->tab[rl]) + (size_t)col * 3u * (size_t)p->ntp * 8u;
         const size_t cb = (size_t)p->ntp * 8u;

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
             }
             // histograms: bin of delta i (1..N) at Julia index i+1; -1 = outside the grid
             for (int i = 1 + lane; i <= N; i += 64) {
-                const long long wi = (long long)__builtin_floor(c.w[rl][i + 1] / p.dwg) - p.wi0;
+                const long long wi = (long long)c.grid_index(c.w[rl][i + 1]) - p.wi0;
                 c.bins[i] = (wi < 0 || wi >= p.n_grid) ? -1 : (int)wi;
             }
             __syncthreads();
@@ -421,7 +421,7 @@ static void fill_params(const sac_edge *h, EdgeParams &p)
     p.hist_copies = h->hist_copies; p.hist_exclusive = h->hist_exclusive ? 1 : 0;
     p.n_grid = c.n_grid; p.wi0 = c.wi_0;
     p.A_c = c.A_c; p.A_r = c.A_r; p.d0 = c.d0; p.w_floor[0] = c.w_floor[0]; p.w_floor[1] = c.w_floor[1];
-    p.w_m = c.w_m; p.dwg = c.d_omega; p.c[0] = c.c[0]; p.c[1] = c.c[1];
+    p.w_m = c.w_m; p.dwg = c.d_omega; p.inv_dwg = 1.0 / c.d_omega; p.c[0] = c.c[0]; p.c[1] = c.c[1];
     p.seed_lo = (uint32_t)c.seed; p.seed_hi = (uint32_t)(c.seed >> 32); p.chain_offset = c.chain_offset;
 }
 
