@@ -410,14 +410,19 @@ struct EdgeChain {
         uint32_t retry = 0;
         const int npair = n / 2;
         const u32x4 pb0 = block(move, iter, (uint32_t)(1 + lane));          // pair q = lane
-        u32x4 pb1 = pb0;
-        if (npair > 64) pb1 = block(move, iter, (uint32_t)(65 + lane));     // pair q = 64 + lane
-        const double pu0 = u01(pb0.z, pb0.w), pu1 = u01(pb1.z, pb1.w);
+        const double pu0 = u01(pb0.z, pb0.w);
         for (int q = 0; q < npair; ++q) {
             const int ql = q & 63;
-            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)((q < 64) ? pb0.x : pb1.x), ql);
-            const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)((q < 64) ? pb0.y : pb1.y), ql);
-            const double U = readlane_f64((q < 64) ? pu0 : pu1, ql);
+            uint32_t wx, wy;
+            double U;
+            if (q < 64) {
+                wx = (uint32_t)__builtin_amdgcn_readlane((int)pb0.x, ql);
+                wy = (uint32_t)__builtin_amdgcn_readlane((int)pb0.y, ql);
+                U = readlane_f64(pu0, ql);
+            } else {                                                        // clusters of more than 128 deltas: rare
+                const u32x4 b = block(move, iter, (uint32_t)(1 + q));
+                wx = b.x; wy = b.y; U = u01(b.z, b.w);
+            }
             const int i = index_from_word(wx, (uint32_t)n);
             int j = index_from_word(wy, (uint32_t)n);
             while (j == i) {
@@ -479,7 +484,7 @@ struct EdgeChain {
             for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
             // the cluster's columns: fetched CH at a time (independent gathers in flight together),
             // accumulated in index order (edge:938-940)
-            constexpr int CH = 4;
+            constexpr int CH = 2;
             for (int j0 = 0; j0 < n; j0 += CH) {
                 double raw[CH][3][NTL], old[CH][NTL], dd[CH], dd2[CH];
 #pragma unroll

@@ -46,7 +46,7 @@ constexpr size_t edge_lds_bytes(int S) { return (size_t)S * (15u * 8u + 3u * 4u)
 // start-of-bin work (zero the bin accumulators and accept counters, Gbar = K_curr A) and the
 // end-of-bin work (record_bin, check_w, adjust_D).  One wave = one chain.
 #ifndef EDGE_WAVES
-#define EDGE_WAVES 2
+#define EDGE_WAVES 3
 #endif
 template <int NTL, bool LOG>
 __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgeParams p)
