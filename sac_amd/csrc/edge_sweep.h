@@ -14,6 +14,9 @@
 namespace sacdev {
 
 enum : int { EDGE_BIN_START = 1, EDGE_BIN_END = 2 };
+// LDS scalar block: per side n0, eps0, dn0, deps0; amplitude_accept_rates[3][2]; bin accumulators
+enum : int { SS_N0 = 0, SS_EPS0 = 2, SS_DN0 = 4, SS_DEPS0 = 6, SS_AMP_AR = 8, SS_CHI2_ACC = 14, SS_EDGE_ACC = 15,
+             SS_N0_ACC = 17, SS_WN0_ACC = 19, SS_COUNT = 24 };
 enum : int { ED_SINGLE = 41, ED_MULTI = 43, ED_MULTI_RETRY = 45, ED_AMP = 47, ED_CONT = 49, ED_CONT_AMP = 50,
              ED_CONT_AMP_RETRY = 51 };
 
@@ -102,7 +105,7 @@ struct EdgeChain {
     uint32_t off[NTL];          // byte offset of this lane's tau element(s) inside a column
     double gbar[NTL], G[NTL], sinv[NTL];
     double chi2, chi2_min;
-    double n0[2], eps0[2], dn0[2], deps0[2], amp_ar[3][2];
+    double *ss;                 // LDS: rarely used wave-uniform scalars (indices SS_*), kept out of the VGPRs
     double wb0[2], wbf[2];
     double inv2theta;
     unsigned long long n_prop, n_eval, n_acc, n_cols;
@@ -565,10 +568,10 @@ struct EdgeChain {
         const u32x4 b0 = block((uint32_t)move, 0, 0);
         const double c = p->c[rl];
         const double eps = (0.69314718055994530942 * c) * (0.69314718055994530942 * c);
-        double n1 = n0[rl], e1 = eps0[rl];
-        n1 += (dn0[rl] * (u01(b0.x, b0.y) - 0.5));
+        double n1 = ss[SS_N0 + rl], e1 = ss[SS_EPS0 + rl];
+        n1 += (ss[SS_DN0 + rl] * (u01(b0.x, b0.y) - 0.5));
         if (n1 < 5 || n1 > (NE - 5)) { rec<LOG>(move, false, false, 0.0); return; }
-        e1 += deps0[rl] * (u01(b0.z, b0.w) - 0.5);
+        e1 += ss[SS_DEPS0 + rl] * (u01(b0.z, b0.w) - 0.5);
         if (e1 < 0 || e1 > 1) { rec<LOG>(move, false, false, 0.0); return; }
         edge_profile<RL>(n1, e1 * eps);
         double gn[NTL], acc_[NTL];
@@ -585,14 +588,12 @@ struct EdgeChain {
         const u32x4 b1 = block((uint32_t)move, 0, 1);
         const bool acc = accept_lt(chi2_new, u01(b1.x, b1.y));
         if (acc) {
-            n0[rl] = n1;
-            eps0[rl] = e1;
+            if (lane == 0) { ss[SS_N0 + rl] = n1; ss[SS_EPS0 + rl] = e1; ss[SS_AMP_AR + rl] += 1; }
             __syncthreads();
             for (int k = 2 + lane; k <= NE + 1; k += 64) A[rl][k] = tempA[k];
 #pragma unroll
             for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
             commit_chi2(chi2_new);
-            amp_ar[0][rl] += 1;
             __syncthreads();
         }
         rec<LOG>(move, true, acc, chi2_new);
@@ -666,7 +667,9 @@ struct EdgeChain {
             }
             rec<LOG>(ED_CONT_AMP, true, acc, chi2_new);
         }
-        amp_ar[1][0] += (double)n_accept / (double)(N - NE);
+        __syncthreads();
+        if (lane == 0) ss[SS_AMP_AR + 2] += (double)n_accept / (double)(N - NE);
+        __syncthreads();
     }
 };
 

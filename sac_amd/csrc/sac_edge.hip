@@ -37,8 +37,9 @@ int efail(int code, const char *fmt, ...)
                          __FILE__, __LINE__);                                              \
     } while (0)
 
-// LDS bytes of one chain: 15 double arrays + 3 int arrays of S entries
-constexpr size_t edge_lds_bytes(int S) { return (size_t)S * (15u * 8u + 3u * 4u) + 64u; }
+// LDS bytes of one chain: per sampled side 6 double arrays, 2 shared double arrays, 3 int arrays of S entries,
+// and the scalar block
+constexpr size_t edge_lds_bytes(int S, int n_rl) { return (size_t)S * ((6u * (unsigned)n_rl + 2u) * 8u + 3u * 4u) + SS_COUNT * 8u + 64u; }
 
 }  // namespace
 
@@ -46,7 +47,7 @@ constexpr size_t edge_lds_bytes(int S) { return (size_t)S * (15u * 8u + 3u * 4u)
 // start-of-bin work (zero the bin accumulators and accept counters, Gbar = K_curr A) and the
 // end-of-bin work (record_bin, check_w, adjust_D).  One wave = one chain.
 #ifndef EDGE_WAVES
-#define EDGE_WAVES 3
+#define EDGE_WAVES 4
 #endif
 template <int NTL, bool LOG>
 __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgeParams p)
@@ -61,26 +62,33 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     c.chain = chain;
     {
         double *d = reinterpret_cast<double *>(s_dyn);
+        c.ss = d; d += SS_COUNT;
         _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
-            c.w[rl] = d; d += S;
-            c.A[rl] = d; d += S;
-            c.dwn[rl] = d; d += S;
-            c.mw[rl] = d; d += S;
-            c.arc[rl][0] = d; d += S;
-            c.arc[rl][1] = d; d += S;
+            if (rl < p.n_rl) {
+                c.w[rl] = d; d += S;
+                c.A[rl] = d; d += S;
+                c.dwn[rl] = d; d += S;
+                c.mw[rl] = d; d += S;
+                c.arc[rl][0] = d; d += S;
+                c.arc[rl][1] = d; d += S;
+            } else {                                       // single-sided modes: side 1 is never touched
+                c.w[rl] = c.w[0]; c.A[rl] = c.A[0]; c.dwn[rl] = c.dwn[0]; c.mw[rl] = c.mw[0];
+                c.arc[rl][0] = c.arc[0][0]; c.arc[rl][1] = c.arc[0][1];
+            }
         }
         c.tmpd = d; d += S;
         c.tmpd2 = d; d += S;
-        c.tempA = d; d += S;
+        c.tempA = c.tmpd2;                                 // amplitude profile and cluster sort never overlap
         int *ip = reinterpret_cast<int *>(d);
         c.nm[0] = ip; ip += S;
-        c.nm[1] = ip; ip += S;
+        c.nm[1] = (p.n_rl == 2) ? ip : c.nm[0];
+        ip += S;
         c.bins = ip;
     }
     const size_t cs = (size_t)chain * 2u * (size_t)S;
     _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
         const size_t o = cs + (size_t)rl * S;
-        for (int k = lane; k < S; k += 64) {
+        if (rl < p.n_rl) for (int k = lane; k < S; k += 64) {
             c.w[rl][k] = p.w[o + k];
             c.A[rl][k] = p.A[o + k];
             c.dwn[rl][k] = p.dw[o + k];
@@ -104,15 +112,18 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     EdgeScalars *scp = p.sc + chain;
     c.chi2 = scp->chi2;
     c.chi2_min = scp->chi2_min;
-    _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
-        c.n0[rl] = scp->n0[rl]; c.eps0[rl] = scp->eps0[rl]; c.dn0[rl] = scp->dn0[rl]; c.deps0[rl] = scp->deps0[rl];
-        _Pragma("unroll") for (int m = 0; m < 3; ++m) c.amp_ar[m][rl] = scp->amp_ar[m][rl];
-        c.wb0[rl] = c.wbf[rl] = p.w_m;
+    if (lane == 0) {
+        for (int rl = 0; rl < 2; ++rl) {
+            c.ss[SS_N0 + rl] = scp->n0[rl]; c.ss[SS_EPS0 + rl] = scp->eps0[rl];
+            c.ss[SS_DN0 + rl] = scp->dn0[rl]; c.ss[SS_DEPS0 + rl] = scp->deps0[rl];
+            for (int m = 0; m < 3; ++m) c.ss[SS_AMP_AR + 2 * m + rl] = scp->amp_ar[m][rl];
+            c.ss[SS_EDGE_ACC + rl] = scp->edge_res[0][rl];
+            c.ss[SS_N0_ACC + rl] = scp->n0_res[0][rl];
+            c.ss[SS_WN0_ACC + rl] = scp->wn0_res[0][rl];
+        }
+        c.ss[SS_CHI2_ACC] = scp->chi2_res[0];
     }
-    double chi2_acc = scp->chi2_res[0];
-    double edge_acc[2] = {scp->edge_res[0][0], scp->edge_res[0][1]};
-    double n0_acc[2] = {scp->n0_res[0][0], scp->n0_res[0][1]};
-    double wn0_acc[2] = {scp->wn0_res[0][0], scp->wn0_res[0][1]};
+    c.wb0[0] = c.wb0[1] = c.wbf[0] = c.wbf[1] = p.w_m;
     unsigned long long sweep = scp->sweep;
     c.inv2theta = p.inv2theta;
     c.chain_id = p.chain_offset + (uint32_t)chain;
@@ -126,10 +137,12 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     __syncthreads();
 
     if (p.flags & EDGE_BIN_START) {                       // edge:1263-1270
-        chi2_acc = 0.0;
+        if (lane == 0) {
+            c.ss[SS_CHI2_ACC] = 0.0;
+            for (int q = SS_EDGE_ACC; q < SS_EDGE_ACC + 6; ++q) c.ss[q] = 0.0;
+        }
         _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
-            edge_acc[rl] = 0.0; n0_acc[rl] = 0.0; wn0_acc[rl] = 0.0;
-            for (int k = lane; k < S; k += 64) { c.arc[rl][0][k] = 0.0; c.arc[rl][1][k] = 0.0; }
+            if (rl < p.n_rl) for (int k = lane; k < S; k += 64) { c.arc[rl][0][k] = 0.0; c.arc[rl][1][k] = 0.0; }
         }
         __syncthreads();
         double acc[NTL];
@@ -172,13 +185,17 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
             c.template amplitude_cont_move<LOG>();
         }
         // measure (edge:1305-1333)
-        chi2_acc += c.chi2;
+        __syncthreads();
+        if (lane == 0) c.ss[SS_CHI2_ACC] += c.chi2;
         _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) if (rl < p.n_rl) {
-            n0_acc[rl] += c.n0[rl] / NE;
-            int idx = (int)__builtin_floor(c.n0[rl]);
-            idx = idx < 1 ? 1 : (idx > N + 1 ? N + 1 : idx);
-            wn0_acc[rl] += c.w[rl][idx];
-            edge_acc[rl] += c.w[rl][2];
+            if (lane == 0) {
+                const double n0v = c.ss[SS_N0 + rl];
+                c.ss[SS_N0_ACC + rl] += n0v / NE;
+                int idx = (int)__builtin_floor(n0v);
+                idx = idx < 1 ? 1 : (idx > N + 1 ? N + 1 : idx);
+                c.ss[SS_WN0_ACC + rl] += c.w[rl][idx];
+                c.ss[SS_EDGE_ACC + rl] += c.w[rl][2];
+            }
             double *wavg = p.wavg + cs + (size_t)rl * S, *aavg = p.aavg + cs + (size_t)rl * S;
             for (int k = 1 + lane; k <= N + 1; k += 64) {
                 aavg[k] += c.A[rl][k];
@@ -217,21 +234,21 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     if (p.flags & EDGE_BIN_END) {
         const double steps = p.steps_in_bin;
         // record_bin (edge:1337-1353)
-        chi2_acc /= steps;
-        const double c1 = chi2_acc;
+        __syncthreads();
         if (lane == 0) {
+            const double c1 = c.ss[SS_CHI2_ACC] / steps;
+            c.ss[SS_CHI2_ACC] = c1;
             scp->chi2_res[1] += c1;
             scp->chi2_res[2] += c1 * c1;
-        }
-        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
-            n0_acc[rl] /= steps; wn0_acc[rl] /= steps; edge_acc[rl] /= steps;
-            if (lane == 0) {
-                scp->n0_res[1][rl] += n0_acc[rl];
-                scp->wn0_res[1][rl] += wn0_acc[rl];
-                scp->edge_res[1][rl] += edge_acc[rl];
-                scp->n0_res[2][rl] += n0_acc[rl] * n0_acc[rl];
-                scp->wn0_res[2][rl] += wn0_acc[rl] * wn0_acc[rl];
-                scp->edge_res[2][rl] += edge_acc[rl] * edge_acc[rl];
+            for (int rl = 0; rl < 2; ++rl) {
+                const double a = c.ss[SS_N0_ACC + rl] / steps, b = c.ss[SS_WN0_ACC + rl] / steps, e = c.ss[SS_EDGE_ACC + rl] / steps;
+                c.ss[SS_N0_ACC + rl] = a; c.ss[SS_WN0_ACC + rl] = b; c.ss[SS_EDGE_ACC + rl] = e;
+                scp->n0_res[1][rl] += a;
+                scp->wn0_res[1][rl] += b;
+                scp->edge_res[1][rl] += e;
+                scp->n0_res[2][rl] += a * a;
+                scp->wn0_res[2][rl] += b * b;
+                scp->edge_res[2][rl] += e * e;
             }
         }
         // check_w (edge:658-718), counted instead of exit()
@@ -274,18 +291,21 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
             if (NE > 3)
                 for (int i = 2 + lane; i <= NE - 1; i += 64)
                     if (c.nm[rl][i] > NE - i) c.nm[rl][i] = NE - i;
-            c.amp_ar[0][rl] /= steps;
-            c.amp_ar[1][rl] /= steps;
-            if (c.amp_ar[0][rl] > 0.55) { c.dn0[rl] *= 1.25; c.deps0[rl] *= 1.25; }
-            else if (c.amp_ar[0][rl] < 0.45) { c.dn0[rl] /= 1.20; c.deps0[rl] /= 1.20; }
+            if (lane == 0) {
+                c.ss[SS_AMP_AR + rl] /= steps;
+                c.ss[SS_AMP_AR + 2 + rl] /= steps;
+                if (c.ss[SS_AMP_AR + rl] > 0.55) { c.ss[SS_DN0 + rl] *= 1.25; c.ss[SS_DEPS0 + rl] *= 1.25; }
+                else if (c.ss[SS_AMP_AR + rl] < 0.45) { c.ss[SS_DN0 + rl] /= 1.20; c.ss[SS_DEPS0 + rl] /= 1.20; }
+            }
         }
         __syncthreads();
     }
 
     // write back
+    __syncthreads();
     _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
         const size_t o = cs + (size_t)rl * S;
-        for (int k = lane; k < S; k += 64) {
+        if (rl < p.n_rl) for (int k = lane; k < S; k += 64) {
             p.w[o + k] = c.w[rl][k];
             p.A[o + k] = c.A[rl][k];
             p.dw[o + k] = c.dwn[rl][k];
@@ -303,14 +323,15 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     if (lane == 0) {
         scp->chi2 = c.chi2;
         scp->chi2_min = c.chi2_min;
-        _Pragma("unroll") for (int rl = 0; rl < 2; ++rl) {
-            scp->n0[rl] = c.n0[rl]; scp->eps0[rl] = c.eps0[rl]; scp->dn0[rl] = c.dn0[rl]; scp->deps0[rl] = c.deps0[rl];
-            _Pragma("unroll") for (int m = 0; m < 3; ++m) scp->amp_ar[m][rl] = c.amp_ar[m][rl];
-            scp->edge_res[0][rl] = edge_acc[rl];
-            scp->n0_res[0][rl] = n0_acc[rl];
-            scp->wn0_res[0][rl] = wn0_acc[rl];
+        for (int rl = 0; rl < 2; ++rl) {
+            scp->n0[rl] = c.ss[SS_N0 + rl]; scp->eps0[rl] = c.ss[SS_EPS0 + rl];
+            scp->dn0[rl] = c.ss[SS_DN0 + rl]; scp->deps0[rl] = c.ss[SS_DEPS0 + rl];
+            for (int m = 0; m < 3; ++m) scp->amp_ar[m][rl] = c.ss[SS_AMP_AR + 2 * m + rl];
+            scp->edge_res[0][rl] = c.ss[SS_EDGE_ACC + rl];
+            scp->n0_res[0][rl] = c.ss[SS_N0_ACC + rl];
+            scp->wn0_res[0][rl] = c.ss[SS_WN0_ACC + rl];
         }
-        scp->chi2_res[0] = chi2_acc;
+        scp->chi2_res[0] = c.ss[SS_CHI2_ACC];
         scp->sweep = sweep;
         scp->counters[0] += c.n_prop;
         scp->counters[1] += c.n_eval;
@@ -656,7 +677,7 @@ static int launch_stage(sac_edge *h, EdgeParams &p)
 {
     const bool log = (h->log_chain >= 0 && h->dLog != nullptr);
     const dim3 grid((unsigned)h->cfg.n_chains), block(64);
-    const size_t lds = edge_lds_bytes(h->S);
+    const size_t lds = edge_lds_bytes(h->S, h->cfg.n_rl);
     const int variant = (h->cfg.n_tau <= 64 ? 0 : 2) | (log ? 1 : 0);
 #define SAC_ELAUNCH(NTL_, LOG_)                                                                          \
     do {                                                                                                 \
