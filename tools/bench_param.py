@@ -18,11 +18,16 @@ from sac_amd.synth import synthetic_timedata  # noqa: E402
 SEED = 777
 
 
-def bench_peak(chains, d_omega=1e-5, n_omega=1000, sweeps=100):
-    """sac/peak, bosonic (one axis), N_tau=64, 10^6+1-column table (512 MB, beyond L2 + Infinity Cache)."""
+def bench_peak(chains, d_omega=1e-5, n_omega=1000, sweeps=100, two_axes=False):
+    """sac/peak, N_tau=64, 10^6+1-column table(s) (488 MiB each, beyond L2 + Infinity Cache); bosonic = one
+    frequency axis, two_axes = fermionic finiteT with both axes and the +/- weight-transfer moves."""
     from sac_amd.peak import PeakProblem
-    td = synthetic_timedata(n_tau=64, seed=SEED)
-    prob = PeakProblem(td, n_omega, 1, 0.5, 10.0, d_omega, kernel_type="bosonic")
+    if two_axes:
+        td = synthetic_timedata(n_tau=64, seed=SEED, kernel_type="finiteT")
+        prob = PeakProblem(td, n_omega, 1, 0.5, 10.0, d_omega, kernel_type="finiteT", approx_ratio=2.5)
+    else:
+        td = synthetic_timedata(n_tau=64, seed=SEED)
+        prob = PeakProblem(td, n_omega, 1, 0.5, 10.0, d_omega, kernel_type="bosonic")
     h = prob.make_handle(n_chains=chains, seed=SEED)
     h.adjust_windows(100, 1.0)
     h.sample(20, 1.0)
@@ -33,10 +38,10 @@ def bench_peak(chains, d_omega=1e-5, n_omega=1000, sweeps=100):
     dt = time.perf_counter() - t0
     cols = s1.columns_gathered - s0.columns_gathered
     kms, nl = s1.last_kernel_ms, s1.last_kernel_launches
-    return {"workload": f"sac/peak bosonic, N_tau=64, {n_omega}+1 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
+    return {"workload": f"sac/peak {'finiteT two axes' if two_axes else 'bosonic'}, N_tau=64, {n_omega}+1 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
                         f"{chains} chains, Theta=1", "chain_sweeps_per_s": chains * sweeps / dt,
             "proposals_per_s": (s1.proposals - s0.proposals) / dt, "accepted_moves_per_s": (s1.accepted_moves - s0.accepted_moves) / dt,
-            "kernel": "peak_stage_kernel<1,false,false>", "launches": nl, "avg_launch_ms": kms / max(nl, 1),
+            "kernel": f"peak_stage_kernel<1,false,{'true' if two_axes else 'false'}>", "launches": nl, "avg_launch_ms": kms / max(nl, 1),
             "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9, "hbm_peak_GBps": 8000.0,
             "frac": cols * 64 * 8 / (kms / 1e3) / 1e9 / 8000.0, "wall_s": dt}
 
@@ -71,5 +76,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.which in ("peak", "both"):
         print(json.dumps(bench_peak(a.chains)), flush=True)
+    if a.which in ("peak2",):
+        print(json.dumps(bench_peak(a.chains, two_axes=True)), flush=True)
     if a.which in ("edge", "both"):
         print(json.dumps(bench_edge(a.chains)), flush=True)
