@@ -3,6 +3,7 @@ write_spec post-processing (free:959-1019) and the Theta_opt rule (free:1249-125
 import os
 
 import numpy as np
+import pytest
 
 from sac_amd.free import FreeSAC, jl_float, _jl_round
 from sac_amd.tin import read_tin
@@ -69,3 +70,61 @@ def test_write_spec_rebin_overlap_trim_and_mirror(tmp_path):
     assert len(body) == 2 * 5
     assert body[0][0] == "-0.2" and body[4][0] == "-0.0" and body[5][0] == "0.0" and body[-1][0] == "0.2"
     assert float(body[5][1]) == coarse[0]
+
+
+# ---- the shipped in-files of the three programs (parameter rows as in sac/*/in_*.in) -----------------
+
+_TAIL = "\n\n######################################################################\n\n1: a comment block follows the rows and is ignored\n"
+
+
+def test_peak_infile_rows_and_folder(tmp_path):
+    from sac_amd.peak import PeakSAC
+    f = tmp_path / "in_peak.in"
+    f.write_text("2000 1\n0.70 15. 0.00001 0.005\n15 1.03 0.5\n250 5000 5000\n../in_files/peak/t_f2.in out_files/fermionic2_v2\n"
+                 "0 0 finiteT\n" + _TAIL)
+    s = PeakSAC.from_infile(str(f))
+    assert (s.N_omega, s.N_p, s.A_0, s.omega_m, s.d_omega, s.d_omega_h) == (2000, 1, 0.7, 15.0, 1e-5, 0.005)
+    assert (s.theta_0, s.f_anneal, s.a_criterion, s.N_anneal, s.anneal_steps, s.sample_steps) == (15.0, 1.03, 0.5, 250, 5000, 5000)
+    assert (s.fix_edge, s.symm, s.kernel_type) == (0, 0, "finiteT")
+    assert s.output_folder == "out_files/fermionic2_v2/Np_01/A0_0.700"                   # peak:1473
+    s = PeakSAC.from_infile(str(f), A_0_in=0.65, N_p_in=2)                             # peak:1573-1575
+    assert s.output_folder.endswith("/Np_02/A0_0.650") and (s.A_0, s.N_p) == (0.65, 2)
+    f.write_text("2000 1\n0.70 15. 0.00001 0.005\n15 1.03 0.5\n250 5000 5000\nx.in out\n0.8 1 finiteT\n")
+    s = PeakSAC.from_infile(str(f))
+    assert (s.fix_edge, s.omega_0, s.symm) == (1, 0.8, 1) and s.output_folder == "out_symm/Np_01/A0_0.700"
+
+
+def test_edge_infile_rows_and_folder(tmp_path):
+    from sac_amd.edge import EdgeSAC
+    f = tmp_path / "in_edge.in"
+    rows = "100 0\n-20.0 20.0 0.005 0.00001\n0.5 0.0 0.5\n10 1.05 200 0.7\n600 10000 20\n../in_files/hchain_beta2048.in out_files/hchain_beta2048\n0 bosonic\nsingle_edge\n"
+    f.write_text(rows + _TAIL)
+    s = EdgeSAC.from_infile(str(f))
+    assert (s.N_e, s.N_c, s.omega_0, s.omega_m, s.d_omega_h, s.d_omega) == (100, 0, 0.0, 20.0, 0.005, 1e-5)   # edge:1888, 1968
+    assert (s.p, s.A_c, s.A_r, s.theta_0, s.f_anneal, s.N_anneal, s.a_criterion) == (0.5, 0.0, 1.0, 10.0, 1.05, 200, 0.7)
+    assert (s.anneal_steps, s.sample_steps, s.bins, s.mode, s.kernel_type) == (600, 10000, 20, "single_edge", "bosonic")
+    assert s.output_folder == "out_files/hchain_beta2048_single/Nw100/Ac_0.000/p_0.500"          # edge:1910-1957
+    f.write_text(rows.replace("0 bosonic\nsingle_edge", "0 finiteT\ndouble_edge_in").replace("0.5 0.0 0.5", "0.4 0.2 0.7"))
+    s = EdgeSAC.from_infile(str(f))
+    assert s.N_c == 50 and s.omega_0 == -20.0                                            # edge:1931-1934: N_c = ceil(N_e / 2)
+    assert s.output_folder == "out_files/hchain_beta2048_double_in/Nw100/Ac_0.200/p_0.400/Ar_0.700"
+    s = EdgeSAC.from_infile(str(f), A_c_in=0.0, A_r_in=0.5, p_in=0.3, scan=True)        # edge:2069-2071
+    assert s.N_c == 0 and s.output_folder == "out_files/hchain_beta2048_double_in/Nw100_scan/Ac_0.000/p_0.300/Ar_0.500"
+    f.write_text(rows.replace("single_edge", "double_edge_symm"))
+    with pytest.raises(ValueError):
+        EdgeSAC.from_infile(str(f))                                                      # edge:1964-1967
+
+
+def test_edge_amplitude_profile_and_initial_scan_product_side():
+    """The product's own host initialisation (sac_amd/edge.py) against the reference's logged answer for
+    hchain_beta2048_single on a 10x coarser grid (the scan does not depend on the grid at this accuracy)."""
+    import os
+    from sac_amd.edge import EdgeProblem, set_amplitudes
+    from sac_amd.tin import read_tin
+    A = set_amplitudes(80, 100, 1 - 2 * 0.3, 60.0, 0.5, 0.25, 0.7, 0)
+    assert A[0] == 0 and A[1:81].sum() == pytest.approx(0.7 / 1.25) and A[81:].sum() == pytest.approx(0.25 / 1.25)
+    assert (np.diff(A[1:81]) > 0).all()                       # c = 1 - 2p > 0: amplitudes grow with the delta index
+    td = read_tin(os.path.join(os.path.dirname(__file__), "golden", "edge", "hchain_single", "t.in"))
+    pr = EdgeProblem(td, "single_edge", "bosonic", 80, 0, 0.5, 0.0, 1.0, 0.0, 20.0, 1e-4)
+    assert (pr.j_opt, pr.k_opt) == (37, 3)                    # log.txt: "Rightward Edge: [1.44, 2.1745...] (37, 3)"
+    assert pr.w[1, 0] == pytest.approx(1.44, abs=1e-12) and pr.w[80, 0] == pytest.approx(2.174545454545454, abs=1e-12)
