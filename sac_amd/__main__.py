@@ -4,7 +4,7 @@ cross_val.jl:514-531): run from a directory holding in_free.in / in_peak.in / in
     python -m sac_amd free  [--chains N] [--seed S]
     python -m sac_amd peak  [A_0 N_p] [--chains N]
     python -m sac_amd edge  [A_c A_r p] [--chains N]
-    python -m sac_amd cv free|peak REP a|b [--chains N]
+    python -m sac_amd cv free|peak|edge REP a|b [--chains N]
 """
 import argparse
 import sys
@@ -31,10 +31,10 @@ def main(argv=None):
         from .edge import EdgeSAC
         v = [float(x) for x in a.args[:3]] + [None] * (3 - len(a.args[:3]))
         return EdgeSAC.from_infile("in_edge.in", A_c_in=v[0], A_r_in=v[1], p_in=v[2], **kw).run("in_edge.in")
-    from .cross_val import free_cv, peak_cv
+    from .cross_val import edge_cv, free_cv, peak_cv
     if len(a.args) < 3:
-        ap.error("cv needs: free|peak REP a|b")
-    fn = {"free": free_cv, "peak": peak_cv}[a.args[0]]
+        ap.error("cv needs: free|peak|edge REP a|b")
+    fn = {"free": free_cv, "peak": peak_cv, "edge": edge_cv}[a.args[0]]
     return fn(int(a.args[1]), a.args[2], **kw)
 
 

@@ -1,5 +1,5 @@
 """Cross-validation wrapper: mirror of sac/cross_validation/cross_val.jl (free_cv cv:6-144,
-peak_cv cv:147-312) above the C ABI.  For replica `rep`, half `ab` it runs the sampler's main anneal
+peak_cv cv:147-312, edge_cv cv:315-509) above the C ABI.  For replica `rep`, half `ab` it runs the sampler's main anneal
 with tol = 1e-6 and appends [Theta, cov * Gbar] to GSAC.csv after every Theta stage (cv:105-108);
 calc_cv.jl then scores half a's Gbar against half b's data.  With n_chains > 1 the row holds the
 chain-averaged Gbar."""
@@ -8,6 +8,7 @@ import shutil
 
 import numpy as np
 
+from .edge import EdgeSAC
 from .free import FreeSAC, _jl_round, jl_float
 from .peak import PeakSAC
 
@@ -94,4 +95,49 @@ def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, **kw):
         _append_gsac(gsac, theta, s.td.cov, g / s.n_chains)
 
     s.run_anneal(s.theta_0, on_stage=dump)
+    return s
+
+
+def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, **kw):
+    """cv:315-509: equilibration, then the full Theta ladder (no stop rule) with one GSAC row per stage."""
+    import math
+    s = EdgeSAC.from_infile(in_file, A_c_in=A_c, A_r_in=A_r, p_in=p, **kw)
+    with open(in_file) as f:
+        rows = [ln.split() for ln in f]
+    G_folder, out = rows[5][0], rows[5][1]
+    s.G_file = "%s/t_%03i%s.in" % (G_folder, rep, ab)               # cv:329-330
+    out += "/%03i%s/edge" % (rep, ab) + "/p_%.3f" % s.p             # cv:330, 362
+    if s.mode in ("double_edge_in", "double_edge_out"):
+        out += "/Ar_%.3f" % s.A_r
+    s.output_folder = out
+    os.makedirs(out, exist_ok=True)
+    gsac = out + "/GSAC.csv"
+    if s.is_root:
+        open(gsac, "w").close()
+    s.write_log("Beginning Initialization.", "w")
+    s.init_outfiles()
+    s.initialize()
+    s.write_log("Running Equillibration Sweeps.")
+    s.run_bins(5 * s.anneal_steps, s.bins, s.theta_0)               # cv:466-467
+    s.write_res(0, s.theta_0)
+    theta, i_trans = s.theta_0, s.N_anneal * 0.2
+    for i in range(1, s.N_anneal + 1):                              # cv:470-500
+        if i < i_trans:
+            steps = int(math.ceil(s.anneal_steps * (1 - ((5 / 6) * i / i_trans))))
+        else:
+            steps = int(math.ceil(s.anneal_steps / 6))
+        s.run_bins(steps, s.bins, theta)
+        s.write_res(i, theta)
+        g = np.zeros(s.td.n_tau)
+        for c in range(s.n_chains):
+            g += s.h.get_gbar(c)[0]
+        g /= s.n_chains
+        if s.comm is not None:
+            tot = s.comm.sum_vector(np.concatenate([g * s.n_chains, [float(s.n_chains)]]))
+            g = tot[:-1] / tot[-1]
+        if s.is_root:
+            _append_gsac(gsac, theta, s.td.cov, g)
+        theta /= s.f_anneal
+        s.chi2_anneal[i - 1] = s.res["chi2_res"][1]
+    s.write_log("Main Anneal Finished.")
     return s

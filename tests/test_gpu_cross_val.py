@@ -76,3 +76,21 @@ def test_peak_cv_and_chain_repair(tmp_path):
     p.sample(20, 5.0)
     assert not np.array_equal(p.h.get_state(2)[0], p.h.get_state(best)[0])     # own Philox stream afterwards
     assert p.repair_chains() == 0
+
+
+def test_edge_cv_gsac(tmp_path):
+    """edge_cv (cv:315-509): equilibration + the whole Theta ladder, one GSAC row per stage."""
+    from sac_amd.cross_val import edge_cv
+    rows = ["24 0", "0.0 6.0 0.05 0.002", "0.5 0.0 1.0", "5 1.5 5 0.5", "60 100 4", f"{CV} {tmp_path}/out", "0 bosonic",
+            "single_edge"]
+    in_file = tmp_path / "in_edge.in"
+    in_file.write_text("\n".join(rows) + "\n")
+    s = edge_cv(1, "a", in_file=str(in_file), n_chains=8, seed=5)
+    assert s.output_folder == f"{tmp_path}/out/001a/edge/p_0.500"
+    got = np.loadtxt(s.output_folder + "/GSAC.csv", delimiter=",")
+    anneal = np.genfromtxt(s.output_folder + "/anneal.csv", delimiter=",", skip_header=1)
+    assert got.shape == (5, 1 + s.td.n_tau) and len(anneal) == 6          # row 0 = equilibration
+    np.testing.assert_allclose(got[:, 0], anneal[1:, 1], rtol=1e-7)
+    td = read_tin(f"{CV}/t_001a.in")
+    assert np.abs(got[-1, 1:] - td.G_raw).max() < 0.05
+    assert s.res["violations"] == 0
