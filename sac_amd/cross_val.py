@@ -141,3 +141,22 @@ def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, **kw):
         s.chi2_anneal[i - 1] = s.res["chi2_res"][1]
     s.write_log("Main Anneal Finished.")
     return s
+
+
+def calc_cv(tin_path, gsac_path):
+    """calc_cv.jl:29-58: chi2 / N_tau of every GSAC row (a half's fitted G(tau) per Theta) against the OTHER half's
+    t.in, in that half's eigenbasis.  Returns (thetas, chi2_val / N_tau)."""
+    from .tin import read_tin
+    td = read_tin(tin_path)
+    rows = np.loadtxt(gsac_path, delimiter=",", ndmin=2)
+    thetas, gsac = rows[:, 0], rows[:, 1:]
+    d = (gsac @ td.cov - td.G) * td.sigma_inv                      # cvcalc:37, 45-51
+    return thetas, (d * d).sum(axis=1) / td.n_tau
+
+
+def cv_score(folder_a, folder_b, tin_a, tin_b):
+    """calc_cv.jl:82-107: validation curve of one replica = mean of (GSAC_b vs t_a) and (GSAC_a vs t_b)."""
+    th, v_ab = calc_cv(tin_a, folder_b + "/GSAC.csv")
+    _, v_ba = calc_cv(tin_b, folder_a + "/GSAC.csv")
+    n = min(len(v_ab), len(v_ba))
+    return th[:n], 0.5 * (v_ab[:n] + v_ba[:n])

@@ -128,3 +128,17 @@ def test_edge_amplitude_profile_and_initial_scan_product_side():
     pr = EdgeProblem(td, "single_edge", "bosonic", 80, 0, 0.5, 0.0, 1.0, 0.0, 20.0, 1e-4)
     assert (pr.j_opt, pr.k_opt) == (37, 3)                    # log.txt: "Rightward Edge: [1.44, 2.1745...] (37, 3)"
     assert pr.w[1, 0] == pytest.approx(1.44, abs=1e-12) and pr.w[80, 0] == pytest.approx(2.174545454545454, abs=1e-12)
+
+
+@pytest.mark.parametrize("rep", [1, 2])
+def test_calc_cv_product_side_known_answer(rep):
+    """sac_amd.cross_val.calc_cv against the reference's committed free_v.csv (same known answer that pins the oracle)."""
+    from sac_amd.cross_val import calc_cv
+    cv = os.path.join(os.path.dirname(__file__), "golden", "cv")
+    exp = np.loadtxt(f"{cv}/free_v_expected.csv", delimiter=",", ndmin=2)
+    th, v_ab = calc_cv(f"{cv}/t_{rep:03d}a.in", f"{cv}/GSAC_free_{rep:03d}b.csv")
+    _, v_ba = calc_cv(f"{cv}/t_{rep:03d}b.in", f"{cv}/GSAC_free_{rep:03d}a.csv")
+    v = 0.5 * (v_ab + v_ba)
+    n = min(len(v), exp.shape[1])
+    np.testing.assert_allclose(th[:n], exp[0][:n], rtol=1e-9)
+    np.testing.assert_allclose(v[:n], exp[rep][:n], rtol=1e-9)
