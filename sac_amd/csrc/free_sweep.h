@@ -281,11 +281,16 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                     const double e2 = e * e;
                     term = (t == 0) ? e2 : (term + e2);
                 }
-                chi2_new = wave_sum_uniform(term);
+                // the sum is complete in lane 63; the Metropolis test is taken there and read off the
+                // compare mask, chi2_new itself comes back to scalar registers only when it is needed
+                const double sum63 = wave_sum_lane63(term);
                 const double ln_u = readlane_f64(d.lnu, j);
-                acc = metropolis(c.chi2, chi2_new, c.inv2theta, ln_u) ? 1 : 0;
+                const unsigned long long am =
+                    __builtin_amdgcn_ballot_w64(metropolis(c.chi2, sum63, c.inv2theta, ln_u));
+                acc = (int)(am >> 63);
                 c.n_eval += 1;
                 c.n_cols += 2 * NCOL;
+                if (LOG || acc) chi2_new = readlane_f64(sum63, 63);
                 if (acc) {                                            // free:310-318
 #pragma unroll
                     for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];

@@ -50,15 +50,23 @@ __device__ __forceinline__ double dpp_bcast_f64(double v)
 // half, whose lanes all hold the same partial sum); then row sums R0..R3: rows 1 and 3 add their
 // predecessor's (row_bcast15: R1+R0, R3+R2), row 3 adds lane 31's (R3+R2)+(R1+R0), and lane 63 is
 // read into scalar registers.  The result is wave-uniform.
-__device__ __forceinline__ double wave_sum_uniform(double v)
+// All levels as in wave_sum_uniform, result valid in lane 63 only (no scalar read-back): for callers that can
+// decide from lane 63 directly.  The two row_bcast levels write every row (lanes without a source read +0):
+// rows 0 and 2 then hold values that are never used, row 3 / lane 63 holds ((R3+R2)+(R1+R0)).
+__device__ __forceinline__ double wave_sum_lane63(double v)
 {
     v = v + dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]  : l ^ 1
     v = v + dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]  : l ^ 2
     v = v + dpp_f64<0x141>(v);   // row_half_mirror      : other quad of the 8-group
     v = v + dpp_f64<0x140>(v);   // row_mirror           : other half of the 16-row
-    v = v + dpp_bcast_f64<0x142, 0xA>(v);   // row_bcast15 into rows 1, 3
-    v = v + dpp_bcast_f64<0x143, 0xC>(v);   // row_bcast31 into rows 2, 3
-    return readlane_f64(v, 63);
+    v = v + dpp_f64<0x142>(v);   // row_bcast15: row r += lane 15 of row r-1  (R1+R0, R3+R2)
+    v = v + dpp_f64<0x143>(v);   // row_bcast31: rows 2, 3 += lane 31         ((R3+R2)+(R1+R0))
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_uniform(double v)
+{
+    return readlane_f64(wave_sum_lane63(v), 63);
 }
 
 // ---- draws -----------------------------------------------------------------------------
