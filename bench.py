@@ -161,7 +161,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes per launch beyond L2, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json",
-                         "kernel": "free_stage_kernel<1,false,true>", "launches": launches,
+                         "kernel": "free_stage_kernel<1,false,true,false>", "launches": launches,
                          "avg_launch_ms": per_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1)},
         }
