@@ -16,7 +16,7 @@ namespace sacdev {
 enum : int { EDGE_BIN_START = 1, EDGE_BIN_END = 2 };
 // LDS scalar block: per side n0, eps0, dn0, deps0; amplitude_accept_rates[3][2]; bin accumulators
 enum : int { SS_N0 = 0, SS_EPS0 = 2, SS_DN0 = 4, SS_DEPS0 = 6, SS_AMP_AR = 8, SS_CHI2_ACC = 14, SS_EDGE_ACC = 15,
-             SS_N0_ACC = 17, SS_WN0_ACC = 19, SS_COUNT = 24 };
+             SS_N0_ACC = 17, SS_WN0_ACC = 19, SS_CNT = 24 /* 4 x u64 */, SS_CHI2_MIN = 28, SS_WB0 = 30, SS_WBF = 32, SS_COUNT = 36 };
 enum : int { ED_SINGLE = 41, ED_MULTI = 43, ED_MULTI_RETRY = 45, ED_AMP = 47, ED_CONT = 49, ED_CONT_AMP = 50,
              ED_CONT_AMP_RETRY = 51 };
 
@@ -104,11 +104,13 @@ struct EdgeChain {
     double *kcurr[2], *knew[2];
     uint32_t off[NTL];          // byte offset of this lane's tau element(s) inside a column
     double gbar[NTL], G[NTL], sinv[NTL];
-    double chi2, chi2_min;
+    double chi2;                // chi2_min: ss[SS_CHI2_MIN]
     double *ss;                 // LDS: rarely used wave-uniform scalars (indices SS_*), kept out of the VGPRs
-    double wb0[2], wbf[2];
     double inv2theta;
-    unsigned long long n_prop, n_eval, n_acc, n_cols;
+    // this sweep's counts, wave-uniform: proposals | evaluated << 21 | accepted << 42 in one word (separate
+    // variables end up in an indexed stack slot), flushed to ss[SS_CNT..] by flush_counts() every sweep
+    unsigned long long cnt;
+    uint32_t n_cols;
     MoveRec *log;
     long long log_cap;
     unsigned long long log_pos;
@@ -118,12 +120,13 @@ struct EdgeChain {
         return philox4x32_10(iter, sweep_lo, sweep_hi | (move << 16) | (b << 24), chain_id, p->seed_lo, p->seed_hi);
     }
 
+    // a condition every lane evaluates alike, as a scalar (branches on it are scalar branches)
+    static __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+
     template <bool LOG>
     __device__ __forceinline__ void rec(int move, bool evaluated, bool accepted, double chi2_new)
     {
-        n_prop += 1;
-        n_eval += evaluated ? 1 : 0;
-        n_acc += accepted ? 1 : 0;
+        cnt += 1ull + ((unsigned long long)(evaluated ? 1 : 0) << 21) + ((unsigned long long)(accepted ? 1 : 0) << 42);
         if constexpr (LOG) {
             if (log != nullptr) {
                 if ((long long)log_pos < log_cap && lane == 0) {
@@ -215,7 +218,21 @@ struct EdgeChain {
     __device__ __forceinline__ void commit_chi2(double chi2_new)
     {
         chi2 = chi2_new;
-        if (chi2_new < chi2_min) chi2_min = chi2_new;
+        if (lane == 0 && chi2_new < ss[SS_CHI2_MIN]) ss[SS_CHI2_MIN] = chi2_new;
+    }
+
+    // once per sweep (a sweep has far fewer than 2^21 proposals)
+    __device__ __forceinline__ void flush_counts()
+    {
+        if (lane == 0) {
+            unsigned long long *cu = reinterpret_cast<unsigned long long *>(ss + SS_CNT);
+            cu[0] += cnt & 0x1FFFFFull;
+            cu[1] += (cnt >> 21) & 0x1FFFFFull;
+            cu[2] += cnt >> 42;
+            cu[3] += n_cols;
+        }
+        cnt = 0;
+        n_cols = 0;
     }
 
     __device__ __forceinline__ double arr_max(const double *a, int lo, int hi) const
@@ -231,77 +248,69 @@ struct EdgeChain {
         return wave_min(m);
     }
 
-    // edge:800-813 (first = 2), edge:907-918 (first = 1)
+    // edge:800-813 (first = 2), edge:907-918 (first = 1); results in ss[SS_WB0 + rl], ss[SS_WBF + rl]
     template <int RL>
     __device__ __forceinline__ void edge_bounds(int first)
     {
         constexpr int rl = RL;
+        double b0, bf;
         if (p->double_in) {
-            wb0[rl] = -arr_max(w[1 - rl], first, p->N + 1);
-            wbf[rl] = -w[1 - rl][2];
+            b0 = -arr_max(w[1 - rl], first, p->N + 1);
+            bf = -w[1 - rl][2];
         } else {
-            wb0[rl] = p->w_m;
-            wbf[rl] = p->w_m;
+            b0 = p->w_m;
+            bf = p->w_m;
         }
         if (p->A_c > 0 && rl == 0 && p->N > p->NE) {
             const double m = arr_min(w[0], p->NE + 2, p->N + 1);
-            wb0[rl] = (m < wb0[rl]) ? m : wb0[rl];
+            b0 = (m < b0) ? m : b0;
         }
+        __syncthreads();
+        if (lane == 0) { ss[SS_WB0 + rl] = b0; ss[SS_WBF + rl] = bf; }
+        __syncthreads();
     }
 
-    // edge:721-784
-    template <int RL>
-    __device__ __forceinline__ int check_order(int k, double wk) const
+    // edge:721-784 on the 5-point neighbourhood x[k-2..k+2] already in registers (xm2, xm1, xp1, xp2)
+    __device__ __forceinline__ bool order_ok(int k, double wk, double xm2, double xm1, double xp1, double xp2) const
     {
-        constexpr int rl = RL;
-        const double *x = w[rl];
         const int NE = p->NE;
         const double d0 = p->d0;
-        double d1, d2, d3, d4;
         if (k == 2) {
-            d1 = x[3] - wk;
-            if (d1 < d0) return 0;
-            if (NE > 2) { d2 = x[4] - x[3]; if (d2 < d1) return 0; }
-        } else if (k == 3) {
-            d1 = wk - x[2];
-            if (d1 < d0) return 0;
-            d2 = -1;
-            if (NE > 2) { d2 = x[4] - wk; if (d2 < d1) return 0; }
-            if (NE > 3) { d3 = x[5] - x[4]; if (d3 < d2) return 0; }
-        } else if (k == NE) {
-            d1 = x[k - 1] - x[k - 2];
-            d2 = wk - x[k - 1];
-            if (d2 < d1) return 0;
-            d3 = x[k + 1] - wk;
-            if (d3 < d2) return 0;
-        } else if (k == NE + 1) {
-            d1 = x[k - 1] - x[k - 2];
-            d2 = wk - x[k - 1];
-            if (d2 < d1) return 0;
-        } else {
-            d1 = x[k - 1] - x[k - 2];
-            d2 = wk - x[k - 1];
-            if (d2 < d1) return 0;
-            d3 = x[k + 1] - wk;
-            if (d3 < d2) return 0;
-            d4 = x[k + 2] - x[k + 1];
-            if (d4 < d3) return 0;
+            const double d1 = xp1 - wk;
+            if (d1 < d0) return false;
+            if (NE > 2) { const double d2 = xp2 - xp1; if (d2 < d1) return false; }
+            return true;
         }
-        return 1;
+        if (k == 3) {
+            const double d1 = wk - xm1;
+            if (d1 < d0) return false;
+            double d2 = -1;
+            if (NE > 2) { d2 = xp1 - wk; if (d2 < d1) return false; }
+            if (NE > 3) { const double d3 = xp2 - xp1; if (d3 < d2) return false; }
+            return true;
+        }
+        const double d1 = xm1 - xm2;
+        const double d2 = wk - xm1;
+        if (d2 < d1) return false;
+        if (k == NE + 1) return true;
+        const double d3 = xp1 - wk;
+        if (d3 < d2) return false;
+        if (k == NE) return true;
+        const double d4 = xp2 - xp1;
+        return !(d4 < d3);
     }
 
     // one-delta proposal shared by single_edge_move and single_cont_move: evaluate, accept, commit
     template <bool LOG, int RL>
-    __device__ __forceinline__ void try_single(int move, int k, double wk, double ln_u)
+    __device__ __forceinline__ void try_single(int move, int k, double wk, double Ak, double ln_u)
     {
         constexpr int rl = RL;
         double kn[NTL], gn[NTL];
         taylor(rl, wk, kn);
-        const double Ak = A[rl][k];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) gn[t] = gbar[t] + Ak * (kn[t] - col_get(kcurr[rl], k, t));
         const double chi2_new = chi2_of(gn);
-        const bool acc = ln_u < (chi2 - chi2_new) * inv2theta;
+        const bool acc = uni(ln_u < (chi2 - chi2_new) * inv2theta);
         if (acc) {
 #pragma unroll
             for (int t = 0; t < NTL; ++t) { gbar[t] = gn[t]; col_put(kcurr[rl], k, t, kn[t]); }
@@ -335,16 +344,19 @@ struct EdgeChain {
                 const int i = base + j;
                 int k = __builtin_amdgcn_readlane(kk, j);
                 if (i % 4 == 0 && p->fix_edge == 0) k = 2;
-                const double wk = x[k] + (dwn[rl][k] * readlane_f64(ush, j));
+                // one LDS round trip: the 5-point neighbourhood of x[k], its window and amplitude
+                const int kp2 = (k + 2 < p->S) ? k + 2 : p->S - 1;
+                const double xk = x[k], xm2 = x[k - 2], xm1 = x[k - 1], xp1 = x[k + 1], xp2 = x[kp2];
+                const double dwk = dwn[rl][k], Ak = A[rl][k], b0 = ss[SS_WB0 + rl], bf = ss[SS_WBF + rl];
+                const double wk = xk + (dwk * readlane_f64(ush, j));
                 bool ok = true;
-                if (k == 2 && wk > wb0[rl]) ok = false;
-                if (ok) {
-                    if (k < NE + 1) { if (wk < x[k - 1] || wk > x[k + 1]) ok = false; }
-                    else { if (wk < x[k - 1] || wk > p->w_m || wk > wbf[rl]) ok = false; }
-                }
-                if (ok) ok = (check_order<RL>(k, wk) == 1);
+                if (k == 2 && wk > b0) ok = false;
+                if (k < NE + 1) { if (wk < xm1 || wk > xp1) ok = false; }
+                else { if (wk < xm1 || wk > p->w_m || wk > bf) ok = false; }
+                if (ok) ok = order_ok(k, wk, xm2, xm1, xp1, xp2);
+                ok = uni(ok);
                 if (!ok) { rec<LOG>(move, false, false, 0.0); continue; }
-                try_single<LOG, RL>(move, k, wk, readlane_f64(lnu, j));
+                try_single<LOG, RL>(move, k, wk, Ak, readlane_f64(lnu, j));
             }
         }
     }
@@ -386,7 +398,7 @@ struct EdgeChain {
         double sum = 0.0;
         for (int i = 0; i < n - 1; ++i) sum = sum + tmpd[i];
         const double w1 = x[n + 1] - sum;
-        if (!(w1 > p->w_floor[rl] && w1 < wb0[rl])) return 0;
+        if (!(w1 > p->w_floor[rl] && w1 < ss[SS_WB0 + rl])) return 0;
         if (n > 2) sort_asc(n - 1);
         double cur = w1;                                   // running position, identical on every lane
         if (lane == 0) m[2] = w1;
@@ -451,7 +463,188 @@ struct EdgeChain {
             if (lane == 0) m[i] = cur;
         }
         __syncthreads();
-        return (m[k + n - 1] < wbf[rl]) ? 1 : 0;
+        return (m[k + n - 1] < ss[SS_WBF + rl]) ? 1 : 0;
+    }
+
+    // ---- clusters of n <= 64 deltas live in registers: lane q holds the q-th spacing / position --------------
+
+    __device__ __forceinline__ double lane_scatter_f64(double v, int dst_lane) const
+    {
+        const uint64_t b = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)(uint32_t)b);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_permute(dst_lane << 2, (int)(uint32_t)(b >> 32));
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    }
+
+    // ascending rank sort of the values of lanes 0..n-1 (ties keep lane order, as sort_asc); other lanes keep theirs
+    __device__ __forceinline__ double lane_sort_asc(double v, int n) const
+    {
+        int r = 0;
+        for (int j = 0; j < n; ++j) {
+            const double o = readlane_f64(v, j);
+            r += (o < v || (o == v && j < lane)) ? 1 : 0;
+        }
+        return lane_scatter_f64(v, (lane < n) ? r : lane);
+    }
+
+    // running positions: lane q gets ((start + t_0) + t_1) ... + t_{q-1}; returns the last one (lane n-1's)
+    __device__ __forceinline__ double lane_running(double start, double t, int n, double &mine) const
+    {
+        double cur = start;
+        mine = start;
+        for (int i = 1; i < n; ++i) {
+            cur = cur + readlane_f64(t, i - 1);
+            mine = (lane == i) ? cur : mine;
+        }
+        return cur;
+    }
+
+    // multi_1 (edge:973-999), 2 <= n <= 64 positions; lane q returns the new w[2 + q] in mine
+    template <int RL>
+    __device__ __forceinline__ int multi_1_reg(int n, uint32_t move, uint32_t iter, double &mine)
+    {
+        constexpr int rl = RL;
+        const double *x = w[rl];
+        const double xa = x[n + 1], xb = x[n + 2];
+        const double d1 = xb - xa;
+        const double d0 = p->d0;
+        const u32x4 b = block(move, iter, (uint32_t)(1 + lane / 2));          // U_u, u = lane
+        const double U = (lane & 1) ? u01(b.z, b.w) : u01(b.x, b.y);
+        double t = d0 + ((d1 - d0) * U);
+        double sum = 0.0;
+        for (int i = 0; i < n - 1; ++i) sum = sum + readlane_f64(t, i);
+        const double w1 = xa - sum;
+        if (!uni(w1 > p->w_floor[rl] && w1 < ss[SS_WB0 + rl])) return 0;
+        if (n > 2) t = lane_sort_asc(t, n - 1);
+        lane_running(w1, t, n, mine);
+        if (lane < n) mw[rl][2 + lane] = mine;
+        return 1;
+    }
+
+    // multi_k (edge:1005-1052), 1 <= n <= 64; lane q returns the new w[k + q] in mine
+    template <int RL>
+    __device__ __forceinline__ int multi_k_reg(int k, int n, uint32_t move, uint32_t iter, double &mine)
+    {
+        constexpr int rl = RL;
+        const double *x = w[rl];
+        const int q0 = (lane < n) ? lane : n - 1;
+        const double xa = x[k + q0], xb = x[k + q0 + 1];
+        const double xkm1 = x[k - 1], xkn1 = x[k + n + 1];
+        double t = xb - xa;                                                  // spacing q of the cluster
+        const double xk = readlane_f64(xa, 0);
+        const double dk_minus1 = xk - xkm1;
+        const double dk_plusn = xkn1 - readlane_f64(xb, n - 1);
+        uint32_t retry = 0;
+        const int npair = n / 2;
+        const u32x4 pb0 = block(move, iter, (uint32_t)(1 + lane));           // pair q = lane
+        const double pu0 = u01(pb0.z, pb0.w);
+        for (int q = 0; q < npair; ++q) {
+            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)pb0.x, q);
+            const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)pb0.y, q);
+            const double U = readlane_f64(pu0, q);
+            const int i = index_from_word(wx, (uint32_t)n);
+            int j = index_from_word(wy, (uint32_t)n);
+            while (j == i) {
+                if (retry > 255) return 0;
+                const u32x4 rb = block(move + (ED_MULTI_RETRY - ED_MULTI), iter, retry++);
+                j = __builtin_amdgcn_readfirstlane(index_from_word(rb.x, (uint32_t)n));
+            }
+            const double di = readlane_f64(t, i), dj = readlane_f64(t, j);
+            const double a = di + dj - dk_plusn, bb = di + dj - dk_minus1;
+            const double d_min = (dk_minus1 > a) ? dk_minus1 : a;
+            const double d_max = (dk_plusn < bb) ? dk_plusn : bb;
+            const double ni = d_min + (d_max - d_min) * U;
+            const double nj = di + dj - ni;
+            t = (lane == i) ? ni : ((lane == j) ? nj : t);
+        }
+        if (n > 1) t = lane_sort_asc(t, n);
+        const double last = lane_running(xk, t, n, mine);
+        if (lane < n) mw[rl][k + lane] = mine;
+        return uni(last < ss[SS_WBF + rl]) ? 1 : 0;
+    }
+
+    // evaluate and accept/reject the cluster k..k+n-1 at the positions held by lanes 0..n-1 (edge:936-966).
+    // Lane q decodes column q (grid index, Taylor offsets, table offset, amplitude); the columns are then
+    // accumulated in index order with CH table rows in flight.
+    template <bool LOG, int RL>
+    __device__ __forceinline__ void cluster_try(uint32_t move, int k, int n, double mine, double ln_u)
+    {
+        constexpr int rl = RL;
+        constexpr int CH = (NTL == 1) ? 4 : 2;
+        const int q0 = (lane < n) ? lane : n - 1;
+        const int wi = grid_index(mine);
+        const double dq = mine - ((double)wi * p->dwg);
+        const double dq2 = dq * dq;
+        long long col = (long long)wi - p->wi0;
+        col = col < 0 ? 0 : (col >= p->n_grid ? p->n_grid - 1 : col);
+        const uint32_t cb = (uint32_t)p->ntp * 8u;
+        const uint64_t boff = (uint64_t)col * (uint64_t)(3u * cb);
+        const double Aq = A[rl][k + q0];
+        const char *tabb = reinterpret_cast<const char *>(p->tab[rl]);
+        const char *kc = reinterpret_cast<const char *>(kcurr[rl]) + (size_t)k * cb;
+        char *kw = reinterpret_cast<char *>(knew[rl]) + (size_t)k * cb;
+        double gn[NTL], raw[CH][3][NTL], old[CH][NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
+        auto fetch = [&](int u, int j) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)boff, j);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(boff >> 32), j);
+            const char *b = tabb + (((uint64_t)hi << 32) | lo);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) raw[u][r][t] = *reinterpret_cast<const double *>(b + r * cb + off[t]);
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) old[u][t] = *reinterpret_cast<const double *>(kc + (uint32_t)j * cb + off[t]);
+        };
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (u < n) fetch(u, u);
+        for (int j0 = 0; j0 < n; j0 += CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = j0 + u;
+                if (j < n) {
+                    const double d = readlane_f64(dq, j), d2 = readlane_f64(dq2, j), Ak = readlane_f64(Aq, j);
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {
+                        const double kn = (raw[u][0][t] + (raw[u][1][t] * d)) + (raw[u][2][t] * d2);
+                        gn[t] = gn[t] + Ak * (kn - old[u][t]);
+                        *reinterpret_cast<double *>(kw + (uint32_t)j * cb + off[t]) = kn;
+                    }
+                    if (j + CH < n) fetch(u, j + CH);
+                }
+            }
+        }
+        n_cols += (uint32_t)n;
+        const double chi2_new = chi2_of(gn);
+        const bool acc = uni(ln_u < (chi2 - chi2_new) * inv2theta);
+        if (acc) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+            for (int j0 = 0; j0 < n; j0 += 4) {                 // K_curr columns <- K_new, four in flight
+                double cp[4][NTL];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = (j0 + u < n) ? j0 + u : n - 1;
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) cp[u][t] = *reinterpret_cast<const double *>(kw + (uint32_t)j * cb + off[t]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j0 + u < n) {
+#pragma unroll
+                        for (int t = 0; t < NTL; ++t)
+                            *reinterpret_cast<double *>(const_cast<char *>(kc) + (uint32_t)(j0 + u) * cb + off[t]) = cp[u][t];
+                    }
+                }
+            }
+            if (lane < n) w[rl][k + lane] = mine;
+            if (lane == 0) arc[rl][1][k] += 1.0;
+            commit_chi2(chi2_new);
+            __syncthreads();
+        }
+        rec<LOG>((int)move, true, acc, chi2_new);
     }
 
     // edge:889-968
@@ -472,15 +665,17 @@ struct EdgeChain {
           for (int jj = 0; jj < cnt; ++jj) {
             const int i = base + jj;
             int k, n, pass;
-            if (i % 4 == 0 && p->fix_edge == 0) {
-                k = 2;
-                n = nm[rl][2];
-                pass = multi_1<RL>(n, move, (uint32_t)i);
-            } else {
-                k = __builtin_amdgcn_readlane(kk, jj);
-                n = nm[rl][k];
-                pass = multi_k<RL>(k, n, move, (uint32_t)i);
+            const bool first = (i % 4 == 0 && p->fix_edge == 0);
+            k = first ? 2 : __builtin_amdgcn_readlane(kk, jj);
+            n = __builtin_amdgcn_readfirstlane(nm[rl][k]);
+            if (n <= 64) {                                   // the usual case: cluster in registers
+                double mine;
+                pass = first ? multi_1_reg<RL>(n, move, (uint32_t)i, mine) : multi_k_reg<RL>(k, n, move, (uint32_t)i, mine);
+                if (pass != 1) { rec<LOG>((int)move, false, false, 0.0); continue; }
+                cluster_try<LOG, RL>(move, k, n, mine, readlane_f64(lnu, jj));
+                continue;
             }
+            pass = first ? multi_1<RL>(n, move, (uint32_t)i) : multi_k<RL>(k, n, move, (uint32_t)i);
             if (pass != 1) { rec<LOG>((int)move, false, false, 0.0); continue; }
             double gn[NTL];
 #pragma unroll
@@ -513,7 +708,7 @@ struct EdgeChain {
                 }
             }
             const double chi2_new = chi2_of(gn);
-            const bool acc = readlane_f64(lnu, jj) < (chi2 - chi2_new) * inv2theta;
+            const bool acc = uni(readlane_f64(lnu, jj) < (chi2 - chi2_new) * inv2theta);
             if (acc) {
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
@@ -586,7 +781,7 @@ struct EdgeChain {
         for (int t = 0; t < NTL; ++t) gn[t] = gbar[t] + acc_[t];
         const double chi2_new = chi2_of(gn);
         const u32x4 b1 = block((uint32_t)move, 0, 1);
-        const bool acc = accept_lt(chi2_new, u01(b1.x, b1.y));
+        const bool acc = uni(accept_lt(chi2_new, u01(b1.x, b1.y)));
         if (acc) {
             if (lane == 0) { ss[SS_N0 + rl] = n1; ss[SS_EPS0 + rl] = e1; ss[SS_AMP_AR + rl] += 1; }
             __syncthreads();
@@ -618,7 +813,7 @@ struct EdgeChain {
                 const int k = __builtin_amdgcn_readlane(kk, j);
                 const double wk = x[k] + (dwn[0][k] * readlane_f64(ush, j));
                 if (wk < wc_min || wk > wc_max) { rec<LOG>(ED_CONT, false, false, 0.0); continue; }
-                try_single<LOG, 0>(ED_CONT, k, wk, readlane_f64(lnu, j));
+                try_single<LOG, 0>(ED_CONT, k, wk, A[0][k], readlane_f64(lnu, j));
             }
         }
     }
@@ -655,7 +850,7 @@ struct EdgeChain {
                 gn[t] = (gbar[t] + dA_j * col_get(kcurr[0], j, t)) + dA_k * col_get(kcurr[0], k, t);
             const double chi2_new = chi2_of(gn);
             const u32x4 b1 = block(ED_CONT_AMP, (uint32_t)i, 1);
-            const bool acc = accept_lt(chi2_new, u01(b1.x, b1.y));
+            const bool acc = uni(accept_lt(chi2_new, u01(b1.x, b1.y)));
             if (acc) {
                 __syncthreads();
                 if (lane == 0) { A[0][j] = A_j + dA_j; A[0][k] = A_k + dA_k; }

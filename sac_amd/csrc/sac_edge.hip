@@ -111,9 +111,11 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     }
     EdgeScalars *scp = p.sc + chain;
     c.chi2 = scp->chi2;
-    c.chi2_min = scp->chi2_min;
     if (lane == 0) {
+        c.ss[SS_CHI2_MIN] = scp->chi2_min;
+        for (int q = 0; q < 4; ++q) reinterpret_cast<unsigned long long *>(c.ss + SS_CNT)[q] = 0ull;
         for (int rl = 0; rl < 2; ++rl) {
+            c.ss[SS_WB0 + rl] = p.w_m; c.ss[SS_WBF + rl] = p.w_m;
             c.ss[SS_N0 + rl] = scp->n0[rl]; c.ss[SS_EPS0 + rl] = scp->eps0[rl];
             c.ss[SS_DN0 + rl] = scp->dn0[rl]; c.ss[SS_DEPS0 + rl] = scp->deps0[rl];
             for (int m = 0; m < 3; ++m) c.ss[SS_AMP_AR + 2 * m + rl] = scp->amp_ar[m][rl];
@@ -123,11 +125,11 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
         }
         c.ss[SS_CHI2_ACC] = scp->chi2_res[0];
     }
-    c.wb0[0] = c.wb0[1] = c.wbf[0] = c.wbf[1] = p.w_m;
     unsigned long long sweep = scp->sweep;
     c.inv2theta = p.inv2theta;
     c.chain_id = p.chain_offset + (uint32_t)chain;
-    c.n_prop = c.n_eval = c.n_acc = c.n_cols = 0;
+    c.cnt = 0;
+    c.n_cols = 0;
     c.log = nullptr;
     c.log_cap = 0;
     c.log_pos = 0;
@@ -227,6 +229,7 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
             }
             __syncthreads();
         }
+        c.flush_counts();
         sweep += 1;
     }
 
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     }
     if (lane == 0) {
         scp->chi2 = c.chi2;
-        scp->chi2_min = c.chi2_min;
+        scp->chi2_min = c.ss[SS_CHI2_MIN];
         for (int rl = 0; rl < 2; ++rl) {
             scp->n0[rl] = c.ss[SS_N0 + rl]; scp->eps0[rl] = c.ss[SS_EPS0 + rl];
             scp->dn0[rl] = c.ss[SS_DN0 + rl]; scp->deps0[rl] = c.ss[SS_DEPS0 + rl];
@@ -333,10 +336,11 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
         }
         scp->chi2_res[0] = c.ss[SS_CHI2_ACC];
         scp->sweep = sweep;
-        scp->counters[0] += c.n_prop;
-        scp->counters[1] += c.n_eval;
-        scp->counters[2] += c.n_acc;
-        scp->counters[4] += c.n_cols;
+        const unsigned long long *cu = reinterpret_cast<const unsigned long long *>(c.ss + SS_CNT);
+        scp->counters[0] += cu[0];
+        scp->counters[1] += cu[1];
+        scp->counters[2] += cu[2];
+        scp->counters[4] += cu[3];
         scp->violations += viol;
         if constexpr (LOG) {
             if (c.log != nullptr) *p.log_len = c.log_pos;

@@ -73,10 +73,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="both")
     ap.add_argument("--chains", type=int, default=4096)
+    ap.add_argument("--d-omega", type=float, default=1e-5)
     a = ap.parse_args()
     if a.which in ("peak", "both"):
-        print(json.dumps(bench_peak(a.chains)), flush=True)
+        print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega)), flush=True)
     if a.which in ("peak2",):
-        print(json.dumps(bench_peak(a.chains, two_axes=True)), flush=True)
+        print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega, two_axes=True)), flush=True)
     if a.which in ("edge", "both"):
-        print(json.dumps(bench_edge(a.chains)), flush=True)
+        print(json.dumps(bench_edge(a.chains, d_omega=a.d_omega)), flush=True)
