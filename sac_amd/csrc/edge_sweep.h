@@ -16,7 +16,12 @@ namespace sacdev {
 enum : int { EDGE_BIN_START = 1, EDGE_BIN_END = 2 };
 // LDS scalar block: per side n0, eps0, dn0, deps0; amplitude_accept_rates[3][2]; bin accumulators
 enum : int { SS_N0 = 0, SS_EPS0 = 2, SS_DN0 = 4, SS_DEPS0 = 6, SS_AMP_AR = 8, SS_CHI2_ACC = 14, SS_EDGE_ACC = 15,
-             SS_N0_ACC = 17, SS_WN0_ACC = 19, SS_CNT = 24 /* 4 x u64 */, SS_CHI2_MIN = 28, SS_WB0 = 30, SS_WBF = 32, SS_COUNT = 36 };
+             SS_N0_ACC = 17, SS_WN0_ACC = 19, SS_CNT = 24 /* 4 x u64 */, SS_CHI2_MIN = 28, SS_WB0 = 30, SS_WBF = 32,
+#ifdef EDGE_PROF
+             SS_PROF = 36, SS_COUNT = 36 + 16 };
+#else
+             SS_COUNT = 36 };
+#endif
 enum : int { ED_SINGLE = 41, ED_MULTI = 43, ED_MULTI_RETRY = 45, ED_AMP = 47, ED_CONT = 49, ED_CONT_AMP = 50,
              ED_CONT_AMP_RETRY = 51 };
 
@@ -92,8 +97,20 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+#ifdef EDGE_PROF   // development aid: cycles per section of chain 0, printed at the end of the launch
+#define EDGE_TICK(i) do { const unsigned long long now_ = clock64(); if (lane == 0) reinterpret_cast<unsigned long long *>(ss + SS_PROF)[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define EDGE_TICK(i) do { } while (0)
+#endif
+
 template <int NTL>
 struct EdgeChain {
+#ifdef EDGE_PROF
+    unsigned long long tprev;
+    __device__ __forceinline__ void tick(int i) { EDGE_TICK(i); }
+#else
+    __device__ __forceinline__ void tick(int) {}
+#endif
     const EdgeParams *p;
     int lane, chain;
     uint32_t chain_id, sweep_lo, sweep_hi;
@@ -207,6 +224,44 @@ struct EdgeChain {
     __device__ __forceinline__ void col_put(double *base, int k, int t, double v) const
     {
         *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + (size_t)k * p->ntp * 8u + off[t]) = v;
+    }
+
+    // acc[t] = acc[t] + K[k][t] * f[k] for k = lo..hi in index order (multiply, then add), a batch of columns in flight
+    __device__ __forceinline__ void cols_dot(const double *K, const double *f, int lo, int hi, double (&acc)[NTL]) const
+    {
+        constexpr int B = (NTL == 1) ? 8 : 4;
+        for (int k0 = lo; k0 <= hi; k0 += B) {
+            double col[B][NTL], fv[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                const int k = (k0 + u <= hi) ? k0 + u : hi;
+                fv[u] = f[k];
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) col[u][t] = col_get(K, k, t);
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                if (k0 + u <= hi) {
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) acc[t] = acc[t] + col[u][t] * fv[u];
+                }
+            }
+        }
+    }
+
+    // a[lo] + a[lo+1] + ... in index order, starting from 0.0; LDS reads eight at a time
+    __device__ __forceinline__ double lds_sum_seq(const double *a, int lo, int hi) const
+    {
+        double sum = 0.0;
+        for (int i0 = lo; i0 <= hi; i0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a[(i0 + u <= hi) ? i0 + u : hi];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u <= hi) sum = sum + v[u];
+        }
+        return sum;
     }
 
     // ln U < (chi2 - chi2_new)/(2 theta)  <=>  rand() < P  (edge:863-864)
@@ -523,7 +578,8 @@ struct EdgeChain {
 
     // multi_k (edge:1005-1052), 1 <= n <= 64; lane q returns the new w[k + q] in mine
     template <int RL>
-    __device__ __forceinline__ int multi_k_reg(int k, int n, uint32_t move, uint32_t iter, double &mine)
+    __device__ __forceinline__ int multi_k_reg(int k, int n, uint32_t move, uint32_t iter, const u32x4 &pair0, const u32x4 &retry0,
+                                               int jj, double &mine)
     {
         constexpr int rl = RL;
         const double *x = w[rl];
@@ -536,18 +592,27 @@ struct EdgeChain {
         const double dk_plusn = xkn1 - readlane_f64(xb, n - 1);
         uint32_t retry = 0;
         const int npair = n / 2;
-        const u32x4 pb0 = block(move, iter, (uint32_t)(1 + lane));           // pair q = lane
-        const double pu0 = u01(pb0.z, pb0.w);
+        // pair 0's block and the first retry block of this iteration were drawn by lane jj of the caller's group
+        // (pair0, retry0); clusters of 4 and more draw pairs 1.. here, pair q on lane q
+        u32x4 pb0 = pair0;
+        int src = jj;
         for (int q = 0; q < npair; ++q) {
-            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)pb0.x, q);
-            const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)pb0.y, q);
-            const double U = readlane_f64(pu0, q);
+            if (q == 1) { pb0 = block(move, iter, (uint32_t)(1 + lane)); src = 1; }
+            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)pb0.x, src);
+            const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)pb0.y, src);
+            const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)pb0.z, src);
+            const uint32_t ww = (uint32_t)__builtin_amdgcn_readlane((int)pb0.w, src);
+            const double U = u01(wz, ww);
+            if (q >= 1) src += 1;
             const int i = index_from_word(wx, (uint32_t)n);
             int j = index_from_word(wy, (uint32_t)n);
             while (j == i) {
                 if (retry > 255) return 0;
-                const u32x4 rb = block(move + (ED_MULTI_RETRY - ED_MULTI), iter, retry++);
-                j = __builtin_amdgcn_readfirstlane(index_from_word(rb.x, (uint32_t)n));
+                uint32_t rx;
+                if (retry == 0) rx = (uint32_t)__builtin_amdgcn_readlane((int)retry0.x, jj);
+                else rx = (uint32_t)__builtin_amdgcn_readfirstlane((int)block(move + (ED_MULTI_RETRY - ED_MULTI), iter, retry).x);
+                retry += 1;
+                j = index_from_word(rx, (uint32_t)n);
             }
             const double di = readlane_f64(t, i), dj = readlane_f64(t, j);
             const double a = di + dj - dk_plusn, bb = di + dj - dk_minus1;
@@ -565,7 +630,7 @@ struct EdgeChain {
 
     // evaluate and accept/reject the cluster k..k+n-1 at the positions held by lanes 0..n-1 (edge:936-966).
     // Lane q decodes column q (grid index, Taylor offsets, table offset, amplitude); the columns are then
-    // accumulated in index order with CH table rows in flight.
+    // accumulated in index order, CH table rows in flight at a time.
     template <bool LOG, int RL>
     __device__ __forceinline__ void cluster_try(uint32_t move, int k, int n, double mine, double ln_u)
     {
@@ -597,10 +662,13 @@ struct EdgeChain {
 #pragma unroll
             for (int t = 0; t < NTL; ++t) old[u][t] = *reinterpret_cast<const double *>(kc + (uint32_t)j * cb + off[t]);
         };
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-            if (u < n) fetch(u, u);
+        EDGE_TICK(5);
+        // batches of CH columns: all loads of a batch are issued (unconditionally, index clamped) before its
+        // first column is consumed
+        const bool small = (n <= CH);               // one batch: the new columns stay in registers, K_new is not used
         for (int j0 = 0; j0 < n; j0 += CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) fetch(u, (j0 + u < n) ? j0 + u : n - 1);
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int j = j0 + u;
@@ -610,19 +678,30 @@ struct EdgeChain {
                     for (int t = 0; t < NTL; ++t) {
                         const double kn = (raw[u][0][t] + (raw[u][1][t] * d)) + (raw[u][2][t] * d2);
                         gn[t] = gn[t] + Ak * (kn - old[u][t]);
-                        *reinterpret_cast<double *>(kw + (uint32_t)j * cb + off[t]) = kn;
+                        raw[u][0][t] = kn;                               // kept for the commit of a small cluster
+                        if (!small) *reinterpret_cast<double *>(kw + (uint32_t)j * cb + off[t]) = kn;
                     }
-                    if (j + CH < n) fetch(u, j + CH);
                 }
             }
         }
         n_cols += (uint32_t)n;
+        EDGE_TICK(6);
         const double chi2_new = chi2_of(gn);
         const bool acc = uni(ln_u < (chi2 - chi2_new) * inv2theta);
+        EDGE_TICK(7);
         if (acc) {
 #pragma unroll
             for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
-            for (int j0 = 0; j0 < n; j0 += 4) {                 // K_curr columns <- K_new, four in flight
+            if (small) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    if (u < n) {
+#pragma unroll
+                        for (int t = 0; t < NTL; ++t)
+                            *reinterpret_cast<double *>(const_cast<char *>(kc) + (uint32_t)u * cb + off[t]) = raw[u][0][t];
+                    }
+                }
+            } else for (int j0 = 0; j0 < n; j0 += 4) {          // K_curr columns <- K_new, four in flight
                 double cp[4][NTL];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -662,17 +741,23 @@ struct EdgeChain {
           const u32x4 b0 = block(move, (uint32_t)(base + lane), 0);      // one iteration per lane
           const int kk = 3 + index_from_word(b0.x, (uint32_t)(NE - 3));
           const double lnu = log_u01(u01(b0.y, b0.z));
+          const u32x4 pair0 = block(move, (uint32_t)(base + lane), 1);   // multi_k: pair 0 and first retry of iteration base + lane
+          const u32x4 retry0 = block(move + (ED_MULTI_RETRY - ED_MULTI), (uint32_t)(base + lane), 0);
           for (int jj = 0; jj < cnt; ++jj) {
             const int i = base + jj;
             int k, n, pass;
+            EDGE_TICK(1);
             const bool first = (i % 4 == 0 && p->fix_edge == 0);
             k = first ? 2 : __builtin_amdgcn_readlane(kk, jj);
             n = __builtin_amdgcn_readfirstlane(nm[rl][k]);
             if (n <= 64) {                                   // the usual case: cluster in registers
                 double mine;
-                pass = first ? multi_1_reg<RL>(n, move, (uint32_t)i, mine) : multi_k_reg<RL>(k, n, move, (uint32_t)i, mine);
+                EDGE_TICK(2);
+                pass = first ? multi_1_reg<RL>(n, move, (uint32_t)i, mine) : multi_k_reg<RL>(k, n, move, (uint32_t)i, pair0, retry0, jj, mine);
+                EDGE_TICK(first ? 3 : 4);
                 if (pass != 1) { rec<LOG>((int)move, false, false, 0.0); continue; }
                 cluster_try<LOG, RL>(move, k, n, mine, readlane_f64(lnu, jj));
+                EDGE_TICK(8);
                 continue;
             }
             pass = first ? multi_1<RL>(n, move, (uint32_t)i) : multi_k<RL>(k, n, move, (uint32_t)i);
@@ -743,8 +828,7 @@ struct EdgeChain {
             tempA[i + 1] = sac_exp(ln_Ai / 2);
         }
         __syncthreads();
-        double sum = 0.0;
-        for (int i = 2; i <= NE + 1; ++i) sum = sum + tempA[i];
+        const double sum = lds_sum_seq(tempA, 2, NE + 1);
         const double f1 = (rl == 0) ? (p->A_r / (1 + p->A_c)) : ((1 - p->A_r) / (1 + p->A_c));
         const double scale = f1 / sum;
         __syncthreads();
@@ -772,11 +856,9 @@ struct EdgeChain {
         double gn[NTL], acc_[NTL];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) acc_[t] = 0.0;
-        for (int k = 2; k <= NE + 1; ++k) {                     // edge:1113-1115
-            const double dA = tempA[k] - A[rl][k];
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) acc_[t] = acc_[t] + col_get(kcurr[rl], k, t) * dA;
-        }
+        for (int k = 2 + lane; k <= NE + 1; k += 64) tmpd[k] = tempA[k] - A[rl][k];
+        __syncthreads();
+        cols_dot(kcurr[rl], tmpd, 2, NE + 1, acc_);             // edge:1113-1115
 #pragma unroll
         for (int t = 0; t < NTL; ++t) gn[t] = gbar[t] + acc_[t];
         const double chi2_new = chi2_of(gn);

@@ -56,8 +56,17 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     const int chain = (int)blockIdx.x;
     const int lane = lane_id();
     const int S = p.S, N = p.N, NE = p.NE;
+    // The hot scalars become values of their own: left as lanes of the wide kernel-argument loads they are
+    // spilled and reloaded a whole tuple at a time inside the move loops.
+    EdgeParams hp = p;
+#define SAC_OWN(x) asm volatile("" : "+s"(x))
+    SAC_OWN(hp.tab[0]); SAC_OWN(hp.tab[1]); SAC_OWN(hp.ntp); SAC_OWN(hp.NE); SAC_OWN(hp.N); SAC_OWN(hp.S);
+    SAC_OWN(hp.double_in); SAC_OWN(hp.fix_edge); SAC_OWN(hp.n_grid); SAC_OWN(hp.wi0); SAC_OWN(hp.A_c); SAC_OWN(hp.A_r);
+    SAC_OWN(hp.d0); SAC_OWN(hp.w_floor[0]); SAC_OWN(hp.w_floor[1]); SAC_OWN(hp.w_m); SAC_OWN(hp.dwg); SAC_OWN(hp.inv_dwg);
+    SAC_OWN(hp.c[0]); SAC_OWN(hp.c[1]); SAC_OWN(hp.seed_lo); SAC_OWN(hp.seed_hi); SAC_OWN(hp.inv2theta);
+#undef SAC_OWN
     EdgeChain<NTL> c;
-    c.p = &p;
+    c.p = &hp;
     c.lane = lane;
     c.chain = chain;
     {
@@ -130,6 +139,10 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     c.chain_id = p.chain_offset + (uint32_t)chain;
     c.cnt = 0;
     c.n_cols = 0;
+#ifdef EDGE_PROF
+    if (lane == 0) for (int q = 0; q < 16; ++q) reinterpret_cast<unsigned long long *>(c.ss + SS_PROF)[q] = 0ull;
+    c.tprev = clock64();
+#endif
     c.log = nullptr;
     c.log_cap = 0;
     c.log_pos = 0;
@@ -150,21 +163,13 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
         double acc[NTL];
 #pragma unroll
         for (int t = 0; t < NTL; ++t) acc[t] = 0.0;
-        for (int k = 1; k <= N + 1; ++k) {                // calc_Gbar!(self, 0), edge:615
-            const double Ak = c.A[0][k];
-#pragma unroll
-            for (int t = 0; t < NTL; ++t) acc[t] = acc[t] + c.col_get(c.kcurr[0], k, t) * Ak;
-        }
+        c.cols_dot(c.kcurr[0], c.A[0], 1, N + 1, acc);    // calc_Gbar!(self, 0), edge:615
 #pragma unroll
         for (int t = 0; t < NTL; ++t) c.gbar[t] = acc[t];
         if (p.n_rl == 2) {                                // edge:618-620
 #pragma unroll
             for (int t = 0; t < NTL; ++t) acc[t] = 0.0;
-            for (int k = 1; k <= N + 1; ++k) {
-                const double Ak = c.A[1][k];
-#pragma unroll
-                for (int t = 0; t < NTL; ++t) acc[t] = acc[t] + c.col_get(c.kcurr[1], k, t) * Ak;
-            }
+            c.cols_dot(c.kcurr[1], c.A[1], 1, N + 1, acc);
 #pragma unroll
             for (int t = 0; t < NTL; ++t) c.gbar[t] = c.gbar[t] + acc[t];
         }
@@ -174,9 +179,13 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     for (int s = 0; s < p.n_sweeps; ++s) {
         c.sweep_lo = (uint32_t)sweep;
         c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
+        c.tick(0);
         c.template single_edge_move<LOG, 0>();            // edge:1273-1281
+        c.tick(10);
         c.template multi_edge_move<LOG, 0>();
+        c.tick(11);
         c.template amplitude_edge_move<LOG, 0>();
+        c.tick(12);
         if (p.n_rl == 2) {
             c.template single_edge_move<LOG, 1>();
             c.template multi_edge_move<LOG, 1>();
@@ -230,9 +239,17 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
             __syncthreads();
         }
         c.flush_counts();
+        c.tick(13);
         sweep += 1;
     }
 
+#ifdef EDGE_PROF
+    if (chain == 0 && lane == 0 && p.n_sweeps > 1) {
+        const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(c.ss + SS_PROF);
+        printf("prof sweeps=%d: start %llu | single %llu multi %llu amp %llu measure %llu | multi: loop %llu disp %llu m1 %llu mk %llu decode %llu gather %llu chi2 %llu commit %llu\n",
+               p.n_sweeps, pr[0], pr[10], pr[11], pr[12], pr[13], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8]);
+    }
+#endif
     unsigned long long viol = 0;
     if (p.flags & EDGE_BIN_END) {
         const double steps = p.steps_in_bin;
