@@ -80,6 +80,39 @@ def test_edge_chain_matches_oracle_move_for_move(case):
     h.close()
 
 
+def test_large_clusters_register_and_lds_paths():
+    """Cluster sizes from 1 to 100 deltas: the register-resident path (n <= 64, several pair blocks and column
+    batches) and the LDS path for longer clusters, both against the oracle."""
+    seed = 77
+    tin, tab, init, o = make_chain("hchain_single", 1e-3, 150, seed=seed, chain=0)
+    NE = init.n_e
+    nm = init.nm.copy()
+    for i in range(2, NE):                                   # Julia index i, array row i - 1
+        nm[i - 1, 0] = max(1, min(100, NE - i - 1, 3 + (i * 7) % 97))
+    nm[1, 0] = 100                                           # the edge cluster of multi_1
+    o.set_state(init.w, init.A, init.dw, nm, init.scalars())
+    o.init_gbar()
+    h = make_handle(tin, tab, init, 1, seed, sweeps_per_launch=3)
+    h.set_state(init.w, init.A, init.dw, nm, init.scalars())
+    h.init_gbar()
+    cap = 200000
+    h.set_move_log(0, cap)
+    o.enable_log(cap)
+    for steps, bins, theta in [(4, 2, 20.0), (4, 2, 2.0)]:
+        h.run_bins(steps, bins, theta)
+        o.run_bins(steps, bins, theta)
+        lg, n = h.move_log(cap)
+        lo = o.log()
+        assert n == len(lo) <= cap
+        bad = np.flatnonzero((lg["move"] != lo["move"]) | (lg["flags"] != lo["flags"]) | (lg["chi2_new"] != lo["chi2_new"]))
+        assert len(bad) == 0, (bad[:5], lg[bad[:3]], lo[bad[:3]])
+        compare(h, o, 0, tab.n_rl)
+    multi = lo[(lo["move"] == 43)]
+    assert ((multi["flags"] & 1) > 0).any()                  # cluster moves were evaluated ...
+    assert ((multi["flags"] & 2) > 0).any()                  # ... and some accepted
+    h.close()
+
+
 def test_chains_are_independent_of_their_neighbours():
     tin, tab, init, _ = make_chain("t2_symm", 2e-3, 24, seed=9)
     h = make_handle(tin, tab, init, 70, 9, sweeps_per_launch=7)
