@@ -278,6 +278,8 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
 #pragma unroll
                         for (int e = 0; e < NE; ++e) { c.wi[s_k[e]] = (uint32_t)s_new[e]; A[s_k[e]] = sAp[e]; }
                     }
+                    // A lives in global memory: later lanes of this wave re-read what lane 0 just stored
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     accepted += 1;
                     c.n_acc += 1;
                     c.n_accmoves += NE;

@@ -226,26 +226,27 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) init_gbar_kernel(const F
 // One launch = n_sweeps sweeps of sac_peak.jl's run_updates (peak:1006-1059) with the per-sweep
 // from-scratch refresh of Gbar/chi2 (peak:1072-1073, 1120-1121), by flag the sampling work
 // (peak:1126-1147) and the window retune (peak:1079-1091).  XFER: the amplitudes change (weight
-// transfer between the axes), so they live in LDS and a block holds two chains.
+// transfer between the axes); they are read and written in place in global memory (16 KB per chain at
+// 2 x 1001 deltas, L2 resident), so that LDS holds the positions only and 16 chains stay resident per CU.
 
 __host__ __device__ constexpr size_t peak_lds_bytes_per_wave(int wi_stride, bool xfer)
 {
-    return (size_t)wi_stride * (xfer ? 12u : 4u) + 26u * 8u;
+    (void)xfer;                     // the transfer variants keep their amplitudes in global memory (L2)
+    return (size_t)wi_stride * 4u + 26u * 8u;
 }
 
 template <int NTL, bool LOG, bool XFER>
-__global__ void __launch_bounds__(64 * (XFER ? 2 : WAVES_PER_BLOCK), XFER ? 2 : 4)
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4)
 peak_stage_kernel(const PeakParams pp)
 {
-    constexpr int WPB = XFER ? 2 : WAVES_PER_BLOCK;
+    constexpr int WPB = WAVES_PER_BLOCK;
     const FreeParams &p = pp.f;
     // dynamic LDS, per wave: [amplitudes f64 x wi_stride (XFER)] [26 f64: windows[11], accept
     // accumulators[11], sum chi2, edge sums[2]] [positions u32 x wi_stride]; sized by peak_lds_bytes()
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *s_mine = s_dyn + (size_t)wave * peak_lds_bytes_per_wave(p.wi_stride, XFER);
-    double *s_A_w = reinterpret_cast<double *>(s_mine);
-    double *s_sc_w = s_A_w + (XFER ? p.wi_stride : 0);
+    double *s_sc_w = reinterpret_cast<double *>(s_mine);
     uint32_t *s_wi_w = reinterpret_cast<uint32_t *>(s_sc_w + 26);
     const int chain = (int)blockIdx.x * WPB + wave;
     if (chain >= p.n_chains) return;
@@ -266,11 +267,7 @@ peak_stage_kernel(const PeakParams pp)
     c.key1 = p.seed_hi;
     c.chain_id = p.chain_offset + (uint32_t)chain;
     double *A_g = p.A + (size_t)chain * (size_t)p.wi_stride;
-    double *A = A_g;
-    if constexpr (XFER) {
-        for (int i = lane; i < n_used; i += 64) s_A_w[i] = A_g[i];
-        A = s_A_w;
-    }
+    double *A = A_g;      // XFER: read and written in place; a chain's 16 KB stay in L2 between its transfer moves
     c.A = A;
     c.A_uniform = 0.0;
     c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
@@ -417,9 +414,6 @@ peak_stage_kernel(const PeakParams pp)
         }
     }
     for (int i = lane; i < n_used; i += 64) wi_g[i] = c.wi[i];
-    if constexpr (XFER) {
-        for (int i = lane; i < n_used; i += 64) A_g[i] = s_A_w[i];
-    }
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const int j = lane + 64 * t;
@@ -1154,7 +1148,7 @@ static int run_peak_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int fl
         }
         HIP_TRY(hipEventRecord(h->kev[li].first, h->stream));
         const bool xfer = h->sample_neg;
-        const int wpb = xfer ? 2 : WAVES_PER_BLOCK;
+        const int wpb = WAVES_PER_BLOCK;
         const dim3 grid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), block(64 * wpb);
         const int variant = (xfer ? 4 : 0) | (h->cfg.n_tau <= 64 ? 0 : 2) | (log ? 1 : 0);
         const size_t lds = (size_t)wpb * peak_lds_bytes_per_wave(h->wi_stride, xfer);
