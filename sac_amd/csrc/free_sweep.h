@@ -490,6 +490,7 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
 #pragma unroll
                         for (int q = 0; q < 2; ++q) { c.wi[s_k[q]] = (uint32_t)s_new[q]; A[s_k[q]] = sAp[q]; }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // A may live in global memory: later lanes re-read it
                     accepted += 1;
                     c.n_acc += 1;
                     c.n_accmoves += 2;
@@ -539,12 +540,14 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
 struct DecodedDA {      // double_A_move: re-split the weight of two deltas at different frequencies
     int k[2], w[2];
     int dead;
-    double r, lnu, dA[2];
+    double r, lnu, dA[2], A[2];     // A: the two amplitudes as decoded (kept current by the re-decode on a hit)
 };
 
 __device__ __forceinline__ void da_compute(DecodedDA &d, const double *A)
 {
     const double A1 = A[d.k[0]], A2 = A[d.k[1]];
+    d.A[0] = A1;
+    d.A[1] = A2;
     const double m0 = A1 + A2;                                      // free:688
     d.dA[0] = (d.r * m0) - A1;                                      // free:692-693
     d.dA[1] = ((1 - d.r) * m0) - A2;
@@ -617,10 +620,12 @@ __device__ __forceinline__ int da_move_loop(Chain<NTL> &c, double *A, int n_it)
                     c.chi2 = chi2_new;
                     if (chi2_new < c.chi2_min) c.chi2_min = chi2_new;
                     const int sk1 = __builtin_amdgcn_readlane(d.k[0], j), sk2 = __builtin_amdgcn_readlane(d.k[1], j);
+                    const double nA1 = readlane_f64(d.A[0], j) + dA1, nA2 = readlane_f64(d.A[1], j) + dA2;   // free:708-709 (+=)
                     if (c.lane == 0) {
-                        A[sk1] = A[sk1] + dA1;                        // free:708-709 (+=)
-                        A[sk2] = A[sk2] + dA2;
+                        A[sk1] = nA1;
+                        A[sk2] = nA2;
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // A may live in global memory: later lanes re-read it
                     accepted += 1;
                     c.n_acc += 1;
                     c.n_accmoves += 2;
@@ -665,6 +670,7 @@ __device__ __forceinline__ void renormalise(double *A, int n, int symm, int lane
     double tot = wave_sum_uniform(part);
     if (symm == 1) tot = 2 * tot;
     for (int i = lane; i < n; i += 64) A[i] = A[i] / tot;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 }  // namespace sacdev

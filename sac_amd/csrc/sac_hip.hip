@@ -25,14 +25,14 @@ using namespace sacdev;
 
 // One launch = n_sweeps sweeps (run_updates, free:825-861) of every chain, plus, by flag, the
 // per-sweep sampling work (free:918-919) and the end-of-round window retune (free:883-895).
-// PAR2 (amplitude updates, free:839-855): the amplitudes join the positions in LDS, two chains per block.
+// PAR2 (amplitude updates, free:839-855): the amplitudes are read and written in place in global memory
+// (16 KB per chain, L2 resident), the positions stay in LDS.
 template <int NTL, bool LOG, bool UA, bool PAR2>
-__global__ void __launch_bounds__(64 * (PAR2 ? 2 : WAVES_PER_BLOCK), PAR2 ? 2 : 4)
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4)
 free_stage_kernel(const FreeParams p)
 {
-    constexpr int WPB = PAR2 ? 2 : WAVES_PER_BLOCK;
+    constexpr int WPB = WAVES_PER_BLOCK;
     __shared__ uint32_t s_wi[WPB][MAX_N_OMEGA];
-    __shared__ double s_A[PAR2 ? WPB : 1][PAR2 ? MAX_N_OMEGA : 1];
     __shared__ double s_sc[WPB][12];   // windows[4], accept accumulators[6], sum chi2
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int chain = (int)blockIdx.x * WPB + wave;
@@ -53,10 +53,6 @@ free_stage_kernel(const FreeParams p)
     c.chain_id = p.chain_offset + (uint32_t)chain;
     double *A_g = p.A + (size_t)chain * (size_t)p.wi_stride;
     c.A = A_g;
-    if constexpr (PAR2) {
-        for (int i = lane; i < p.n_omega; i += 64) s_A[wave][i] = A_g[i];
-        c.A = s_A[wave];
-    }
     c.A_uniform = p.A_uniform;
     c.n_eval = c.n_acc = c.n_accmoves = c.n_cols = 0;
     double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
@@ -111,7 +107,7 @@ free_stage_kernel(const FreeParams p)
         if (lane == 0) acc[2] += (double)a / (double)(n / 3);
 #endif
         if constexpr (PAR2) {
-            double *A = s_A[wave];
+            double *A = A_g;
             a = aw_move_loop<(NTL == 1) ? 4 : 2, NTL, LOG>(c, A, n / 2, win[3]);   // free:851-852
             if (lane == 0) acc[3] += (double)(2 * a) / (double)(n / 2);
             renormalise(A, n, p.symm, lane);                        // free:563-567
@@ -149,9 +145,6 @@ free_stage_kernel(const FreeParams p)
     }
 
     for (int i = lane; i < p.n_omega; i += 64) wi_g[i] = c.wi[i];
-    if constexpr (PAR2) {
-        for (int i = lane; i < p.n_omega; i += 64) A_g[i] = s_A[wave][i];
-    }
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const int j = lane + 64 * t;
@@ -992,7 +985,7 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
         HIP_TRY(hipEventRecord(h->kev[li].first, h->stream));
         const bool par2 = (h->cfg.par == 2);
         const bool ua = h->uniform_A && !par2;
-        const int wpb = par2 ? 2 : WAVES_PER_BLOCK;
+        const int wpb = WAVES_PER_BLOCK;
         const dim3 grid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), block(64 * wpb);
         const int variant = (par2 ? 8 : 0) | (h->cfg.n_tau <= 64 ? 0 : 4) | (log ? 2 : 0) | (ua ? 1 : 0);
 #define SAC_LAUNCH(NTL_, LOG_, UA_, P2_) \

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsac_hip.so")
+LIB_PATH = os.environ.get("SAC_HIP_LIB") or os.path.join(_HERE, "libsac_hip.so")   # SAC_HIP_LIB: another build of the same library
 _LIB = None
 
 EXPORTS = [

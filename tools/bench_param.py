@@ -46,6 +46,28 @@ def bench_peak(chains, d_omega=1e-5, n_omega=1000, sweeps=100, two_axes=False):
             "frac": cols * 64 * 8 / (kms / 1e3) / 1e9 / 8000.0, "wall_s": dt}
 
 
+def bench_free2(chains, d_omega=1e-4, n_omega=2000, sweeps=100):
+    """sac/free with amplitude updates (par = 2: A_w_move, double_A_move, renormalisation), BASELINE configs[1] shape."""
+    from sac_amd.free import FreeProblem
+    td = synthetic_timedata(n_tau=64, seed=SEED)
+    prob = FreeProblem(td, n_omega, 0.0, 10.0, d_omega, par=2, kernel_type="bosonic")
+    h = prob.make_handle(n_chains=chains, seed=SEED)
+    h.adjust_windows(100, 1.0)
+    h.sample(20, 1.0)
+    s0 = h.stats()
+    t0 = time.perf_counter()
+    h.sample(sweeps, 1.0)
+    s1 = h.stats()
+    dt = time.perf_counter() - t0
+    cols = s1.columns_gathered - s0.columns_gathered
+    kms, nl = s1.last_kernel_ms, s1.last_kernel_launches
+    return {"workload": f"sac/free par=2 bosonic, N_tau=64, {n_omega} deltas, {prob.n_grid}-column table, {chains} chains, Theta=1",
+            "chain_sweeps_per_s": chains * sweeps / dt, "proposals_per_s": (s1.proposals - s0.proposals) / dt,
+            "accepted_moves_per_s": (s1.accepted_moves - s0.accepted_moves) / dt,
+            "kernel": "free_stage_kernel<1,false,false,true>", "launches": nl, "avg_launch_ms": kms / max(nl, 1),
+            "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9, "wall_s": dt}
+
+
 def bench_edge(chains, d_omega=1e-5, n_e=80, steps=40, bins=4):
     """sac/edge single_edge, N_tau=64, N_e=80, three 10^6+1-column tables interleaved (1.5 GB)."""
     from sac_amd.edge import EdgeProblem
@@ -79,5 +101,7 @@ if __name__ == "__main__":
         print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega)), flush=True)
     if a.which in ("peak2",):
         print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega, two_axes=True)), flush=True)
+    if a.which in ("free2",):
+        print(json.dumps(bench_free2(a.chains)), flush=True)
     if a.which in ("edge", "both"):
         print(json.dumps(bench_edge(a.chains, d_omega=a.d_omega)), flush=True)
