@@ -5,6 +5,8 @@ cross_val.jl:514-531): run from a directory holding in_free.in / in_peak.in / in
     python -m sac_amd peak  [A_0 N_p] [--chains N]
     python -m sac_amd edge  [A_c A_r p] [--chains N]
     python -m sac_amd cv free|peak|edge REP a|b [--chains N]
+    python -m torch.distributed.run --nproc-per-node G -m sac_amd cv-all REP_FIRST REP_LAST [free,peak,edge]
+        (replicas x halves x parameterisations round-robin over the G GPUs; in-files in the working directory)
 """
 import argparse
 import sys
@@ -12,7 +14,7 @@ import sys
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m sac_amd")
-    ap.add_argument("program", choices=["free", "peak", "edge", "cv"])
+    ap.add_argument("program", choices=["free", "peak", "edge", "cv", "cv-all"])
     ap.add_argument("args", nargs="*")
     ap.add_argument("--chains", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
@@ -31,6 +33,27 @@ def main(argv=None):
         from .edge import EdgeSAC
         v = [float(x) for x in a.args[:3]] + [None] * (3 - len(a.args[:3]))
         return EdgeSAC.from_infile("in_edge.in", A_c_in=v[0], A_r_in=v[1], p_in=v[2], **kw).run("in_edge.in")
+    if a.program == "cv-all":
+        import os
+        from .cross_val import cv_units, run_cv_partition
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        kw["device"] = int(os.environ.get("LOCAL_RANK", str(a.device)))
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(kw["device"])
+            dist.init_process_group("nccl", device_id=torch.device("cuda", kw["device"]))
+        if len(a.args) < 2:
+            ap.error("cv-all needs: REP_FIRST REP_LAST [free,peak,edge]")
+        params = tuple(a.args[2].split(",")) if len(a.args) > 2 else ("free", "peak", "edge")
+        units = cv_units(range(int(a.args[0]), int(a.args[1]) + 1), params)
+        folders = run_cv_partition(units, rank, world, **kw)
+        if rank == 0:
+            for u in units:
+                print(u, folders[u])
+        if world > 1:
+            dist.destroy_process_group()
+        return folders
     from .cross_val import edge_cv, free_cv, peak_cv
     if len(a.args) < 3:
         ap.error("cv needs: free|peak|edge REP a|b")

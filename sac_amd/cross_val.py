@@ -160,3 +160,58 @@ def cv_score(folder_a, folder_b, tin_a, tin_b):
     _, v_ba = calc_cv(tin_b, folder_a + "/GSAC.csv")
     n = min(len(v_ab), len(v_ba))
     return th[:n], 0.5 * (v_ab[:n] + v_ba[:n])
+
+
+# ---- cross-validation units over the GPUs of a node (run_cv.sh fans the same units out as
+# separate Julia processes) --------------------------------------------------------------------------------
+
+def cv_units(reps, params=("free", "peak", "edge")):
+    """The independent units of a K-fold run: (parameterisation, replica, half)."""
+    return [(prm, int(rep), ab) for rep in reps for ab in ("a", "b") for prm in params]
+
+
+def partition_units(units, rank, world):
+    """Round-robin: unit i runs on rank i % world (whole GPUs per unit, no communication while it runs)."""
+    return list(units[rank::world])
+
+
+def run_cv_partition(units, rank=0, world=1, runner=None, gather=None, **kw):
+    """Runs this rank's share of `units` and returns, on every rank, {unit: output folder} for all units.
+    runner(unit, **kw) -> output folder; default = free_cv / peak_cv / edge_cv on this rank's GPU.
+    gather(obj) -> list of every rank's obj (default: torch.distributed.all_gather_object when world > 1)."""
+    if runner is None:
+        def runner(unit, **k):
+            prm, rep, ab = unit
+            return {"free": free_cv, "peak": peak_cv, "edge": edge_cv}[prm](rep, ab, **k).output_folder
+    mine = {}
+    for unit in partition_units(units, rank, world):
+        mine[unit] = runner(unit, **kw)
+    if world == 1:
+        return mine
+    if gather is None:
+        import torch.distributed as dist
+
+        def gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+    merged = {}
+    for part in gather(mine):
+        merged.update(part)
+    missing = [u for u in units if u not in merged]
+    if missing:
+        raise RuntimeError(f"cross-validation units without a result: {missing}")
+    return merged
+
+
+def cv_curves(folders, tin_folder, params=("free", "peak", "edge")):
+    """Validation curves per (parameterisation, replica) from the folders run_cv_partition returns
+    (calc_cv.jl:82-107): {(prm, rep): (thetas, chi2_val / N_tau)}."""
+    out = {}
+    for prm in params:
+        for rep in sorted({u[1] for u in folders if u[0] == prm}):
+            fa, fb = folders.get((prm, rep, "a")), folders.get((prm, rep, "b"))
+            if fa is None or fb is None:
+                continue
+            out[(prm, rep)] = cv_score(fa, fb, "%s/t_%03ia.in" % (tin_folder, rep), "%s/t_%03ib.in" % (tin_folder, rep))
+    return out

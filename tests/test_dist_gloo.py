@@ -105,3 +105,49 @@ def test_merge_named_two_ranks():
         assert r["chi2"] == pytest.approx(allc[:, 0, 0].mean(), rel=1e-13)
         assert r["chi2_min"] == allc.min()
         assert r["violations"] == 3
+
+
+# ---- cross-validation units partitioned over ranks (BASELINE configs[4]) -----------------------------------
+
+def _cv_worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import shutil
+    from sac_amd.cross_val import cv_curves, cv_units, run_cv_partition
+    cv = os.path.join(os.path.dirname(__file__), "golden", "cv")
+    ran = []
+
+    def runner(unit, **kw):
+        # stands in for free_cv on a GPU: "produces" the reference's committed GSAC.csv of that unit
+        prm, rep, ab = unit
+        folder = os.path.join(tmp, "%03i%s" % (rep, ab), prm)
+        os.makedirs(folder, exist_ok=True)
+        shutil.copyfile("%s/GSAC_%s_%03i%s.csv" % (cv, prm, rep, ab), folder + "/GSAC.csv")
+        ran.append(unit)
+        return folder
+
+    units = cv_units([1, 2], params=("free",))
+    folders = run_cv_partition(units, rank, world, runner=runner)
+    curves = cv_curves(folders, cv, params=("free",)) if rank == 0 else {}
+    out[rank] = dict(ran=ran, n=len(folders), curves={k: (v[0].tolist(), v[1].tolist()) for k, v in curves.items()})
+    dist.destroy_process_group()
+
+
+def test_cv_units_round_robin_over_two_ranks(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cv_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    # 2 replicas x 2 halves x 1 parameterisation = 4 units: disjoint, covering, alternating
+    assert sorted(r0["ran"] + r1["ran"]) == sorted([("free", 1, "a"), ("free", 1, "b"), ("free", 2, "a"), ("free", 2, "b")])
+    assert len(r0["ran"]) == len(r1["ran"]) == 2 and not set(map(tuple, r0["ran"])) & set(map(tuple, r1["ran"]))
+    assert r0["n"] == r1["n"] == 4                              # every rank learns every unit's folder
+    exp = np.loadtxt(os.path.join(os.path.dirname(__file__), "golden", "cv", "free_v_expected.csv"), delimiter=",", ndmin=2)
+    for rep in (1, 2):                                          # root scores them: the reference's free_v.csv
+        th, v = r0["curves"][("free", rep)]
+        n = min(len(v), exp.shape[1])
+        np.testing.assert_allclose(th[:n], exp[0][:n], rtol=1e-9)
+        np.testing.assert_allclose(v[:n], exp[rep][:n], rtol=1e-9)
