@@ -1,0 +1,22 @@
+# rocprofv3 counter passes (one --pmc set per run) for the three stage kernels; summaries go to profiles/ by hand
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/pmc_f
+mkdir -p $O
+run() {   # name, counters, program args...
+  local name=$1 ctr=$2; shift 2
+  timeout -s KILL 150 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o p -- python3 "$@" > $O/$name.log 2>&1
+  echo "$name done"
+}
+P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"
+P3="FETCH_SIZE GRBM_GUI_ACTIVE"
+P4="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+P2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
+FREE="$R/bench.py --steps 3 --warmup 1 --no-cpu"
+EDGE="$R/tools/bench_param.py edge"
+PEAK="$R/tools/bench_param.py peak"
+run free_p1 "$P1" $FREE && run free_p3 "$P3" $FREE && run free_p4 "$P4" $FREE && \
+run edge_p1 "$P1" $EDGE && run edge_p3 "$P3" $EDGE && run edge_p4 "$P4" $EDGE && \
+run peak_p1 "$P1" $PEAK && run peak_p3 "$P3" $PEAK && run peak_p4 "$P4" $PEAK && \
+run free_p2 "$P2" $FREE && run edge_p2 "$P2" $EDGE && run peak_p2 "$P2" $PEAK
