@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--chains", type=int, default=CHAINS_PER_GPU)
     ap.add_argument("--sweeps-per-step", type=int, default=SWEEPS_PER_STEP)
     ap.add_argument("--d-omega", type=float, default=D_OMEGA)
+    ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = the library's default")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -68,9 +69,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # SAC_BENCH_REHEARSE=1 (development only, never a reported number): ranks share the GPUs that exist and merge
+    # over gloo, to walk the N>1 code path on a one-GPU box; the driver's runs use RCCL, one GPU per rank.
+    rehearse = os.environ.get("SAC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if rehearse:
+            c = t.cpu()
+            dist.all_reduce(c, op=op)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=op)
 
     from sac_amd.free import FreeProblem
     from sac_amd.synth import synthetic_timedata
@@ -78,7 +95,7 @@ def main():
     prob = FreeProblem(td, N_OMEGA, 0.0, OMEGA_M, args.d_omega, par=1, kernel_type="bosonic")
     # chains are block-partitioned over ranks; the Philox key holds the global chain id
     h = prob.make_handle(n_chains=args.chains, seed=SEED, chain_offset=rank * args.chains,
-                         device=local_rank)
+                         device=local_rank, sweeps_per_launch=args.sweeps_per_launch)
     h.adjust_windows(250, THETA)             # equilibrate + tune the windows (untimed; 10 x 25 sweeps)
 
     hist_dev = torch.zeros(prob.n_grid, dtype=torch.float64, device="cuda")
@@ -93,9 +110,9 @@ def main():
             st = h.stats()
             stat_dev.copy_(torch.tensor([st.sampled_chi2, *st.accept_rates, 1.0], dtype=torch.float64))
             min_dev.fill_(st.chi2_min)
-            dist.all_reduce(hist_dev)
-            dist.all_reduce(stat_dev)
-            dist.all_reduce(min_dev, op=dist.ReduceOp.MIN)
+            all_reduce(hist_dev)
+            all_reduce(stat_dev)
+            all_reduce(min_dev, op=dist.ReduceOp.MIN)
 
     def fence():
         if world > 1:
@@ -122,8 +139,8 @@ def main():
                           s1.evaluated - s0.evaluated], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = local[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(local)
+        all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(local)
         local[0] = tmax[0]
     dt_max, moves, props, sweeps, cols, evald = (float(x) for x in local.cpu())
 
@@ -149,7 +166,7 @@ def main():
             "value": moves / dt_max, "unit": "accepted delta-moves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: ranks share a GPU, gloo merge -- not a result)",
             "config": {"workload": "sac/free bosonic, N_tau=64, 2000 delta-functions, "
                                    f"{prob.n_grid}-point omega grid, {args.chains} chains per MI355X, Theta=1 "
                                    "(BASELINE.json configs[1])",

@@ -112,6 +112,7 @@ struct EdgeChain {
     __device__ __forceinline__ void tick(int) {}
 #endif
     const EdgeParams *p;
+    WavePriority prio;          // rotated per group of iterations of the move loops (wave_ops.h)
     int lane, chain;
     uint32_t chain_id, sweep_lo, sweep_hi;
     // LDS (per side arrays of S entries)
@@ -389,6 +390,7 @@ struct EdgeChain {
         // draws of 64 iterations at a time, one iteration per lane (Philox blocks 0 and 1, U - 1/2, ln U);
         // the sequential loop below reads them with v_readlane
         for (int base = 1; base <= NE; base += 64) {
+            prio.rotate();
             const int cnt = (NE - base + 1 < 64) ? (NE - base + 1) : 64;
             const u32x4 b0 = block((uint32_t)move, (uint32_t)(base + lane), 0);
             const u32x4 b1 = block((uint32_t)move, (uint32_t)(base + lane), 1);
@@ -745,6 +747,7 @@ struct EdgeChain {
           const u32x4 retry0 = block(move + (ED_MULTI_RETRY - ED_MULTI), (uint32_t)(base + lane), 0);
           for (int jj = 0; jj < cnt; ++jj) {
             const int i = base + jj;
+            if ((jj & 15) == 0) prio.rotate();
             int k, n, pass;
             EDGE_TICK(1);
             const bool first = (i % 4 == 0 && p->fix_edge == 0);
@@ -885,6 +888,7 @@ struct EdgeChain {
         const double *x = w[0];
         const double wc_min = x[2], wc_max = x[NE + 1];
         for (int base = 0; base < N - NE; base += 64) {
+            prio.rotate();
             const int cnt = (N - NE - base < 64) ? (N - NE - base) : 64;
             const u32x4 b0 = block(ED_CONT, (uint32_t)(base + lane), 0);
             const u32x4 b1 = block(ED_CONT, (uint32_t)(base + lane), 1);

@@ -66,6 +66,7 @@ constexpr int MAX_N_OMEGA = 2048;
 // Per-wave state that lives in registers for the whole launch.
 template <int NTL>
 struct Chain {
+    WavePriority prio;          // rotated once per group of 64 proposals (wave_ops.h)
     const char *Kb;             // K table, byte addressed
     uint32_t col_bytes;         // bytes per (padded) column
     uint32_t *wi;               // LDS
@@ -208,6 +209,7 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
 {
     int accepted = 0;
     for (int base = 0; base < n_it; base += 64) {
+        c.prio.rotate();
         const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
         Decoded<NCOL, UA> d;
         decode<NCOL, NTL, UA>(c, MOVE, (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1)), window, d);
@@ -388,6 +390,7 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
     constexpr int MOVE = 4;
     int accepted = 0;
     for (int base = 0; base < n_it; base += 64) {
+        c.prio.rotate();
         const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
         DecodedAW d;
         {
@@ -559,6 +562,7 @@ __device__ __forceinline__ int da_move_loop(Chain<NTL> &c, double *A, int n_it)
     constexpr int MOVE = 5;
     int accepted = 0;
     for (int base = 0; base < n_it; base += 64) {
+        c.prio.rotate();
         const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
         DecodedDA d;
         {

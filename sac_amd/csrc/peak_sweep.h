@@ -167,6 +167,7 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
     int accepted = 0;
     const char *keep = c.Kb;
     for (int base = 0; base < n_it; base += 64) {
+        c.prio.rotate();
         const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
         DecodedX<NPAIR> d;
         {

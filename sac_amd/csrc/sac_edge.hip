@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     EdgeChain<NTL> c;
     c.p = &hp;
     c.lane = lane;
+    c.prio.init();
     c.chain = chain;
     {
         double *d = reinterpret_cast<double *>(s_dyn);
@@ -374,6 +375,7 @@ __global__ void __launch_bounds__(64) edge_init_kernel(const EdgeParams p)
     EdgeChain<NTL> c;
     c.p = &p;
     c.lane = lane;
+    c.prio.init();
     c.n_cols = 0;
     const size_t cs = (size_t)chain * 2u * (size_t)S;
 #pragma unroll

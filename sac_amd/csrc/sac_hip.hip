@@ -44,6 +44,7 @@ free_stage_kernel(const FreeParams p)
     c.col_bytes = (uint32_t)p.ntp * 8u;
     c.wi = s_wi[wave];
     c.lane = lane;
+    c.prio.init();
     c.n_omega = p.n_omega;
     c.gmax = p.gmax;
     c.k_first = 0; c.k_count = p.n_omega; c.lo = 0; c.hi = p.gmax;
@@ -253,6 +254,7 @@ peak_stage_kernel(const PeakParams pp)
     c.col_bytes = (uint32_t)p.ntp * 8u;
     c.wi = s_wi_w;
     c.lane = lane;
+    c.prio.init();
     c.n_omega = n;
     c.gmax = pp.wim;
     c.inv2theta = p.inv2theta;
@@ -447,6 +449,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const P
     c.col_bytes = (uint32_t)p.ntp * 8u;
     c.wi = p.wi + (size_t)chain * (size_t)p.wi_stride;   // read in place (one pass)
     c.lane = lane;
+    c.prio.init();
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const int j = lane + 64 * t;
