@@ -148,6 +148,31 @@ int sac_get_histogram(sac_handle_t *h, double *out);
  * (e.g. a tensor handed to an RCCL all-reduce); *steps_times_chains receives the divisor. */
 int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, double *steps_times_chains);
 
+/* ---- K table built on the device ------------------------------------
+ * Replaces the table loop of initialize! / init_kernal! (free:199-213, peak:248-276, edge:167-236):
+ * K[i][t] = sum_j kernel(w_i, tau_j) * U[j][t], w_i = ((i_first + i) + offset) * d_omega, i = 0 .. n_grid-1
+ * (elementwise kernel, then the basis change as one fp64 MFMA product).  Not bit-identical to a table the
+ * host built (other exp, other summation order); sac_get_table returns exactly what the device uses. */
+#define SAC_KERNEL_FINITE_T 0
+#define SAC_KERNEL_ZERO_T   1
+#define SAC_KERNEL_BOSONIC  2
+typedef struct {
+    int32_t kernel_type;    /* SAC_KERNEL_* (free:220-239) */
+    int32_t mirror;         /* 1: K(w) + K(-w) (symm: free:206-208, peak:258-262, edge:223) */
+    int32_t negate;         /* 1: evaluate at -w (negative axis: peak:270-272, edge's R side) */
+    int32_t reserved;
+    int64_t i_first;        /* grid index of row 0 (free: min(wi_0, 0); peak: 0; edge: wi_0) */
+    double  offset;         /* 0, or 0.5 on peak's half-offset grid (peak:253) */
+    double  d_omega, beta;
+} sac_table_spec_t;
+/* which = 0: K_array (free) / Kp_array (peak); 1: Kn_array (peak).  tau[n_tau]; U[n_tau][n_tau] row-major = the
+ * reference's `cov` (eigenvectors in columns, free:107-108). */
+int sac_build_table(sac_handle_t *h, int32_t which, const sac_table_spec_t *spec, const double *tau, const double *U);
+/* out[n_grid][n_tau], tau contiguous: the table as the device holds it (uploaded or built). */
+int sac_get_table(sac_handle_t *h, int32_t which, double *out);
+/* G = U^T G and sigma_inv (free:123, 110) without a table: completes a problem whose table(s) sac_build_table made. */
+int sac_upload_data(sac_handle_t *h, const double *G, const double *sigma_inv);
+
 /* ---- SAC_KIND_PEAK ------------------------------------------------------------------------- */
 /* Kp_array / Kn_array of initialize! (peak:248-276), each [wi_m + 1][n_tau], tau contiguous; Kn may
  * be NULL when only the positive axis is sampled (symm or bosonic). */
@@ -235,6 +260,14 @@ int sac_edge_destroy(sac_edge_t *h);
 /* K_array, dK_array, d2K_array of init_kernal! (edge:167-242): per side a [N_tau, N_wi] column-major slice */
 int sac_edge_upload_problem(sac_edge_t *h, const double *const *K, const double *const *dK,
                             const double *const *d2K, const double *G, const double *sigma_inv);
+/* Row f1 for edge: K of side `side` (0 = L, 1 = R) built on the device as sac_build_table does (spec->i_first = wi_0,
+ * spec->negate = 1 for the R side, spec->mirror = 1 for double_edge_symm), then dK and d2K by the reference's
+ * stencils (edge:230-235, incl. the row the reference addresses as wi_m + 1).  Call once per sampled side, then
+ * sac_edge_upload_data. */
+int sac_edge_build_tables(sac_edge_t *h, int32_t side, const sac_table_spec_t *spec, const double *tau, const double *U);
+int sac_edge_upload_data(sac_edge_t *h, const double *G, const double *sigma_inv);
+/* K, dK, d2K of one side as the device holds them, each [n_grid][n_tau] (any may be NULL) */
+int sac_edge_get_tables(sac_edge_t *h, int32_t side, double *K, double *dK, double *d2K);
 /* omega_array, A_array, D_omega_array, n_multi (edge:51-53, 72-73); scal8 = n0[2], eps_0[2], Dn0[2], Deps_0[2]
  * (edge:24-27).  chain = -1: all chains.  Any pointer may be NULL (left unchanged).  Also what
  * anneal_and_sample's save/restore needs (edge:1671-1675, 1724-1726). */

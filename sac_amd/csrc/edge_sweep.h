@@ -58,31 +58,6 @@ struct EdgeParams {
     double steps_in_bin, inv2theta;
 };
 
-// exp(x), |x| < 700: fdlibm e_exp.c scheme, IEEE operations in this fixed order (oracle: sac_exp)
-__device__ __forceinline__ double sac_exp(double x)
-{
-    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
-                 P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
-    double hi = x, lo = 0.0;
-    int k = 0;
-    if (__builtin_fabs(x) > 0.34657359027997264) {
-        k = (int)(invln2 * x + ((x < 0.0) ? -0.5 : 0.5));
-        const double t = (double)k;
-        hi = x - t * ln2HI;
-        lo = t * ln2LO;
-    }
-    const double r = hi - lo;
-    const double t = r * r;
-    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - ((r * c) / (c - 2.0) - r);
-    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
-    uint64_t b = __builtin_bit_cast(uint64_t, y);
-    b += (uint64_t)((int64_t)k << 52);
-    return __builtin_bit_cast(double, b);
-}
-
 __device__ __forceinline__ double wave_min(double v)
 {
 #pragma unroll

@@ -12,6 +12,7 @@
 
 #include "../../include/sac_hip.h"
 #include "edge_sweep.h"
+#include "table_build.h"
 
 using namespace sacdev;
 
@@ -440,6 +441,7 @@ struct sac_edge {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool problem = false, state_set = false, gbar_set = false;
+    bool table_built[2] = {false, false};   // sac_edge_build_tables
     int64_t last_steps = 0, last_bins = 0;
     double last_stage_ms = 0.0;
 };
@@ -585,6 +587,87 @@ extern "C" int sac_edge_upload_problem(sac_edge_t *h, const double *const *K, co
     std::memcpy(pad, sigma_inv, nt * sizeof(double));
     HIP_TRY(hipMemcpy(h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
     h->problem = true;
+    return SAC_OK;
+}
+
+static int upload_data(sac_edge *h, const double *G, const double *sigma_inv)
+{
+    const size_t nt = (size_t)h->cfg.n_tau;
+    double pad[SAC_MAX_N_TAU];
+    std::memset(pad, 0, sizeof(pad));
+    std::memcpy(pad, G, nt * sizeof(double));
+    HIP_TRY(hipMemcpy(h->dG, pad, sizeof(pad), hipMemcpyHostToDevice));
+    std::memset(pad, 0, sizeof(pad));
+    std::memcpy(pad, sigma_inv, nt * sizeof(double));
+    HIP_TRY(hipMemcpy(h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_upload_data(sac_edge_t *h, const double *G, const double *sigma_inv)
+{
+    if (!h || !G || !sigma_inv) return efail(SAC_E_INVALID, "sac_edge_upload_data: null argument");
+    for (int rl = 0; rl < h->cfg.n_rl; ++rl)
+        if (!h->table_built[rl]) return efail(SAC_E_STATE, "sac_edge_upload_data: build the tables of side %d first", rl);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    if ((rc = upload_data(h, G, sigma_inv))) return rc;
+    h->problem = true;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_build_tables(sac_edge_t *h, int32_t side, const sac_table_spec_t *spec, const double *tau, const double *U)
+{
+    if (!h || !spec || !tau || !U) return efail(SAC_E_INVALID, "sac_edge_build_tables: null argument");
+    if (side < 0 || side >= h->cfg.n_rl) return efail(SAC_E_INVALID, "sac_edge_build_tables: side %d outside 0..%d", side, h->cfg.n_rl - 1);
+    if (spec->kernel_type < 0 || spec->kernel_type > 2) return efail(SAC_E_INVALID, "sac_edge_build_tables: Invalid Kernel type.");   // edge:191
+    if (!(spec->d_omega > 0) || !std::isfinite(spec->beta)) return efail(SAC_E_INVALID, "sac_edge_build_tables: d_omega=%g beta=%g", spec->d_omega, spec->beta);
+    if (spec->i_first != h->cfg.wi_0) return efail(SAC_E_INVALID, "sac_edge_build_tables: i_first=%lld, the handle's wi_0 is %lld", (long long)spec->i_first, (long long)h->cfg.wi_0);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const size_t ng = (size_t)h->cfg.n_grid, nt = (size_t)h->cfg.n_tau, ntp = (size_t)h->ntp;
+    if (!h->dTab[side]) HIP_TRY(hipMalloc((void **)&h->dTab[side], ng * 3 * ntp * sizeof(double)));
+    double *d_tau = nullptr, *d_U = nullptr;
+    HIP_TRY(hipMalloc(&d_tau, nt * sizeof(double)));
+    if (hipMalloc(&d_U, nt * nt * sizeof(double)) != hipSuccess) { (void)hipFree(d_tau); return efail(SAC_E_HIP, "sac_edge_build_tables: out of device memory"); }
+    hipError_t e = hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        TableSpec sp;
+        sp.kernel_type = spec->kernel_type; sp.n_tau = (int)nt; sp.mirror = spec->mirror; sp.negate = spec->negate;
+        sp.i_first = spec->i_first; sp.offset = spec->offset; sp.d_omega = spec->d_omega; sp.beta = spec->beta;
+        sp.n_grid = (long long)ng; sp.ld = 3 * (int)ntp; sp.n_cols = (int)ntp;
+        e = launch_table_build(h->stream, sp, d_tau, d_U, h->dTab[side]);
+        if (e == hipSuccess) {
+            const double dw = spec->d_omega;
+            const long long idx_m = h->cfg.wi_0 + (long long)ng - 1;          // wi_m: the reference's index wi_m + 1, 0-based
+            const long long total = (long long)ng * (long long)ntp;
+            hipLaunchKernelGGL(edge_stencil_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                               h->dTab[side], (long long)ng, (int)ntp, idx_m, dw, 2 * dw, 2 * (dw * dw));
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(d_tau);
+    (void)hipFree(d_U);
+    if (e != hipSuccess) return efail(SAC_E_HIP, "sac_edge_build_tables: %s", hipGetErrorString(e));
+    h->table_built[side] = true;
+    h->gbar_set = false;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_tables(sac_edge_t *h, int32_t side, double *K, double *dK, double *d2K)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_get_tables: null handle");
+    if (side < 0 || side >= h->cfg.n_rl || !h->dTab[side]) return efail(SAC_E_INVALID, "sac_edge_get_tables: side %d has no table", side);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t ng = (size_t)h->cfg.n_grid, nt = (size_t)h->cfg.n_tau, ntp = (size_t)h->ntp;
+    double *dst[3] = {K, dK, d2K};
+    for (int q = 0; q < 3; ++q)
+        if (dst[q])
+            HIP_TRY(hipMemcpy2D(dst[q], nt * sizeof(double), h->dTab[side] + (size_t)q * ntp, 3 * ntp * sizeof(double),
+                                nt * sizeof(double), ng, hipMemcpyDeviceToHost));
     return SAC_OK;
 }
 

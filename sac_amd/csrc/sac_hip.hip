@@ -16,6 +16,7 @@
 #include "free_sweep.h"
 #include "hist_sort.h"
 #include "peak_sweep.h"
+#include "table_build.h"
 
 using namespace sacdev;
 
@@ -607,6 +608,7 @@ struct sac_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;   // reusable per-launch event pairs
     bool problem = false, state_set = false, gbar_set = false;
+    bool table_built[2] = {false, false};   // sac_build_table
     bool uniform_A = false;
     double A_uniform = 0.0;
     // layout of one chain's state as the caller sees it
@@ -761,6 +763,72 @@ extern "C" int sac_upload_problem(sac_handle_t *h, const double *K, const double
     HIP_TRY(hipMemcpy(h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
     h->problem = true;
+    return SAC_OK;
+}
+
+extern "C" int sac_upload_data(sac_handle_t *h, const double *G, const double *sigma_inv)
+{
+    if (!h || !G || !sigma_inv) return fail(SAC_E_INVALID, "sac_upload_data: null argument");
+    if (!h->table_built[0] || (h->peak && h->sample_neg && !h->table_built[1]))
+        return fail(SAC_E_STATE, "sac_upload_data: build the table(s) first (sac_build_table)");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t nt = (size_t)h->cfg.n_tau;
+    for (size_t j = 0; j < nt; ++j)
+        if (!std::isfinite(G[j]) || !std::isfinite(sigma_inv[j]))
+            return fail(SAC_E_INVALID, "sac_upload_data: non-finite G or sigma_inv at tau index %zu", j);
+    HIP_TRY(hipMemcpy(h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
+    h->problem = true;
+    return SAC_OK;
+}
+
+extern "C" int sac_build_table(sac_handle_t *h, int32_t which, const sac_table_spec_t *spec, const double *tau, const double *U)
+{
+    if (!h || !spec || !tau || !U) return fail(SAC_E_INVALID, "sac_build_table: null argument");
+    if (which < 0 || which > 1 || (which == 1 && !h->dKn))
+        return fail(SAC_E_INVALID, "sac_build_table: table %d does not exist on this handle", which);
+    if (spec->kernel_type < 0 || spec->kernel_type > 2)
+        return fail(SAC_E_INVALID, "sac_build_table: Invalid Kernel type.");           // free:195
+    if (!(spec->d_omega > 0) || !std::isfinite(spec->beta) || !std::isfinite(spec->offset))
+        return fail(SAC_E_INVALID, "sac_build_table: d_omega=%g beta=%g offset=%g", spec->d_omega, spec->beta, spec->offset);
+    int rc = use_device(h);
+    if (rc) return rc;
+    const size_t nt = (size_t)h->cfg.n_tau;
+    for (size_t j = 0; j < nt; ++j)
+        if (!std::isfinite(tau[j])) return fail(SAC_E_INVALID, "sac_build_table: non-finite tau[%zu]", j);
+    double *d_tau = nullptr, *d_U = nullptr;
+    HIP_TRY(hipMalloc(&d_tau, nt * sizeof(double)));
+    if (hipMalloc(&d_U, nt * nt * sizeof(double)) != hipSuccess) { (void)hipFree(d_tau); return fail(SAC_E_HIP, "sac_build_table: out of device memory"); }
+    hipError_t e = hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        TableSpec sp;
+        sp.kernel_type = spec->kernel_type; sp.n_tau = (int)nt; sp.mirror = spec->mirror; sp.negate = spec->negate;
+        sp.i_first = spec->i_first; sp.offset = spec->offset; sp.d_omega = spec->d_omega; sp.beta = spec->beta;
+        sp.n_grid = h->cfg.n_grid; sp.ld = h->ntp; sp.n_cols = h->ntp;
+        e = launch_table_build(h->stream, sp, d_tau, d_U, which == 0 ? h->dK : h->dKn);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(d_tau);
+    (void)hipFree(d_U);
+    if (e != hipSuccess) return fail(SAC_E_HIP, "sac_build_table: %s", hipGetErrorString(e));
+    h->table_built[which] = true;
+    h->gbar_set = false;
+    return SAC_OK;
+}
+
+extern "C" int sac_get_table(sac_handle_t *h, int32_t which, double *out)
+{
+    if (!h || !out) return fail(SAC_E_INVALID, "sac_get_table: null argument");
+    if (which < 0 || which > 1 || (which == 1 && !h->dKn))
+        return fail(SAC_E_INVALID, "sac_get_table: table %d does not exist on this handle", which);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t nt = (size_t)h->cfg.n_tau, ng = (size_t)h->cfg.n_grid;
+    HIP_TRY(hipMemcpy2D(out, nt * sizeof(double), which == 0 ? h->dK : h->dKn, (size_t)h->ntp * sizeof(double),
+                        nt * sizeof(double), ng, hipMemcpyDeviceToHost));
     return SAC_OK;
 }
 

@@ -203,12 +203,21 @@ class EdgeProblem:
     def scalars(self):
         return np.concatenate([self.n0, self.eps0, self.dn0, self.deps0])
 
-    def make_handle(self, n_chains=1, seed=0, **kw):
+    def make_handle(self, n_chains=1, seed=0, device_tables=False, **kw):
+        """device_tables: K, dK, d2K built on the GPU (sac_edge_build_tables) instead of uploading the host-built
+        ones (the host tables still serve the initial scan, edge:399-583)."""
         k = self.kernel
         h = SacEdgeHandle(self.td.n_tau, self.n_e, self.n_omega, k.n_grid, k.wi0, k.dw, self.w_m, self.w_floor, self.c,
                           n_rl=k.n_rl, double_in=int(self.mode == "double_edge_in"), fix_edge=self.fix_edge,
                           A_c=self.A_c, A_r=self.A_r, d0=self.d0, n_chains=n_chains, seed=seed, **kw)
-        h.upload_problem(k.tables, self.td.G, self.td.sigma_inv)
+        if device_tables:
+            td = self.td
+            for rl in range(k.n_rl):
+                h.build_tables(rl, k.kernel_type, td.tau, td.beta, td.cov, k.wi0, k.dw,
+                               mirror=int(k.mode == "double_edge_symm"), negate=int(rl == 1))
+            h.upload_data(td.G, td.sigma_inv)
+        else:
+            h.upload_problem(k.tables, self.td.G, self.td.sigma_inv)
         nm = np.where(self.nm < 0, 0, self.nm)                              # the -1 markers (edge:572) are never read
         h.set_state(self.w, self.A, self.dwin, nm, self.scalars())
         h.init_gbar()

@@ -34,7 +34,14 @@ class FreeProblem:
         self.wi = start + step * i                                   # free:166
         A = np.ones(self.n_omega) if par in (1, 2) else i.astype(np.float64)   # free:168-172
         self.A = A / (2 * A.sum()) if symm == 1 else A / A.sum()     # free:176-183
-        self.K = self._kernel_table()
+        self._K = None
+
+    @property
+    def K(self):
+        """The host-built table (built on first use: device_tables=True never needs it)."""
+        if self._K is None:
+            self._K = self._kernel_table()
+        return self._K
 
     def _kernel_table(self):
         """free:199-213: K(omega_i, tau) rotated into the covariance eigenbasis, tau contiguous."""
@@ -49,11 +56,17 @@ class FreeProblem:
             K[a:a + len(w)] = kv @ td.cov                            # free:212 (U^T K[:, i])
         return K
 
-    def make_handle(self, n_chains=1, seed=0, **kw):
-        """SAC(...) + read_G! + initialize! + calc_Gbar/calc_chi2 + default windows (free:1191-1218)."""
+    def make_handle(self, n_chains=1, seed=0, device_tables=False, **kw):
+        """SAC(...) + read_G! + initialize! + calc_Gbar/calc_chi2 + default windows (free:1191-1218).
+        device_tables: build the K table on the GPU (sac_build_table) instead of uploading the host-built one."""
         h = SacHandle(self.td.n_tau, self.n_omega, self.n_grid, self.wi_0, self.wi_m,
                       n_chains=n_chains, par=self.par, symm=self.symm, seed=seed, **kw)
-        h.upload_problem(self.K, self.td.G, self.td.sigma_inv)
+        if device_tables:
+            h.build_table(0, self.kernel_type, self.td.tau, self.td.beta, self.td.cov, self.wi_0, self.d_omega,
+                          mirror=int(self.symm == 1))
+            h.upload_data(self.td.G, self.td.sigma_inv)
+        else:
+            h.upload_problem(self.K, self.td.G, self.td.sigma_inv)
         h.set_state(self.wi, self.A, np.full(4, self.window))
         h.init_gbar()
         return h

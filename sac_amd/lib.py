@@ -19,6 +19,8 @@ EXPORTS = [
     "sac_edge_init_gbar", "sac_edge_run_bins", "sac_edge_get_results", "sac_edge_get_accept_rates",
     "sac_edge_get_histogram", "sac_edge_get_avg", "sac_edge_get_gbar", "sac_edge_set_move_log",
     "sac_edge_get_move_log",
+    "sac_build_table", "sac_get_table", "sac_upload_data",
+    "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -78,6 +80,21 @@ class EdgeResults(C.Structure):
                 ("last_stage_ms", C.c_double)]
 
 
+KERNEL_TYPES = {"finiteT": 0, "zeroT": 1, "bosonic": 2}
+
+
+class TableSpec(C.Structure):
+    """sac_table_spec_t"""
+    _fields_ = [("kernel_type", C.c_int32), ("mirror", C.c_int32), ("negate", C.c_int32), ("reserved", C.c_int32),
+                ("i_first", C.c_int64), ("offset", C.c_double), ("d_omega", C.c_double), ("beta", C.c_double)]
+
+
+def _table_spec(kernel_type, i_first, d_omega, beta, offset=0.0, mirror=0, negate=0):
+    if kernel_type not in KERNEL_TYPES:
+        raise ValueError("Invalid Kernel type.")
+    return TableSpec(KERNEL_TYPES[kernel_type], int(mirror), int(negate), 0, int(i_first), float(offset), float(d_omega), float(beta))
+
+
 PROPOSAL = np.dtype([("move", "<i4"), ("k", "<i4", 3), ("w_new", "<i8", 3), ("u", "<f8")])
 
 MOVE_REC = np.dtype([("chi2_new", "<f8"), ("flags", "<i4"), ("move", "<i4")])
@@ -120,6 +137,12 @@ def load_library():
     L.sac_copy_chain.argtypes = [vp, C.c_int32, C.c_int32]
     L.sac_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_get_chain_chi2.argtypes = [vp, dp, dp]
+    L.sac_build_table.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
+    L.sac_get_table.argtypes = [vp, C.c_int32, dp]
+    L.sac_upload_data.argtypes = [vp, dp, dp]
+    L.sac_edge_build_tables.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
+    L.sac_edge_upload_data.argtypes = [vp, dp, dp]
+    L.sac_edge_get_tables.argtypes = [vp, C.c_int32, dp, dp, dp]
     pdp = C.POINTER(dp)
     L.sac_edge_create.argtypes = [C.POINTER(EdgeConfig), C.POINTER(vp)]
     L.sac_edge_destroy.argtypes = [vp]
@@ -243,6 +266,27 @@ class SacHandle:
                     edge_mean=o[4:6].copy())
 
     # ---- SAC_KIND_PEAK ----------------------------------------------------------------------
+    def build_table(self, which, kernel_type, tau, beta, U, i_first, d_omega, offset=0.0, mirror=0, negate=0):
+        """K table built on the device (sac_build_table): which = 0 K / Kp, 1 Kn; U = the reference's `cov`."""
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        if tau.shape != (self.n_tau,) or U.shape != (self.n_tau, self.n_tau):
+            raise SacError("tau must have n_tau entries and U n_tau x n_tau")
+        sp = _table_spec(kernel_type, i_first, d_omega, beta, offset, mirror, negate)
+        self._check(self.L.sac_build_table(self.h, int(which), C.byref(sp), _dp(tau), _dp(U)))
+
+    def get_table(self, which=0):
+        out = np.empty((self.n_grid, self.n_tau))
+        self._check(self.L.sac_get_table(self.h, int(which), _dp(out)))
+        return out
+
+    def upload_data(self, G, sigma_inv):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        sigma_inv = np.ascontiguousarray(sigma_inv, dtype=np.float64)
+        if G.shape != (self.n_tau,) or sigma_inv.shape != (self.n_tau,):
+            raise SacError("G and sigma_inv must have n_tau entries")
+        self._check(self.L.sac_upload_data(self.h, _dp(G), _dp(sigma_inv)))
+
     def upload_problem_peak(self, Kp, Kn, G, sigma_inv):
         Kp = np.ascontiguousarray(Kp, dtype=np.float64)
         Kn = None if Kn is None else np.ascontiguousarray(Kn, dtype=np.float64)
@@ -345,6 +389,25 @@ class SacEdgeHandle:
             self.close()
         except Exception:
             pass
+
+    def build_tables(self, side, kernel_type, tau, beta, U, i_first, d_omega, mirror=0, negate=0):
+        """K, dK, d2K of one side built on the device (sac_edge_build_tables)."""
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        if tau.shape != (self.n_tau,) or U.shape != (self.n_tau, self.n_tau):
+            raise SacError("tau must have n_tau entries and U n_tau x n_tau")
+        sp = _table_spec(kernel_type, i_first, d_omega, beta, 0.0, mirror, negate)
+        self._check(self.L.sac_edge_build_tables(self.h, int(side), C.byref(sp), _dp(tau), _dp(U)))
+
+    def upload_data(self, G, sigma_inv):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        sigma_inv = np.ascontiguousarray(sigma_inv, dtype=np.float64)
+        self._check(self.L.sac_edge_upload_data(self.h, _dp(G), _dp(sigma_inv)))
+
+    def get_tables(self, side):
+        out = [np.empty((self.n_grid, self.n_tau)) for _ in range(3)]
+        self._check(self.L.sac_edge_get_tables(self.h, int(side), _dp(out[0]), _dp(out[1]), _dp(out[2])))
+        return tuple(out)
 
     def upload_problem(self, tables, G, sigma_inv):
         """tables: per side (K, dK, d2K), each [n_grid, n_tau] C-order (= Julia's [N_tau, N_wi] slices)."""

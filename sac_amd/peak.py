@@ -76,7 +76,20 @@ class PeakProblem:
         else:
             A = A / A.sum()                                          # peak:229
         self.wi, self.A = wi, A
-        self.Kp, self.Kn = self._kernel_tables()
+        self._tables = None
+
+    @property
+    def Kp(self):
+        """Host-built tables, built on first use (device_tables=True never needs them)."""
+        if self._tables is None:
+            self._tables = self._kernel_tables()
+        return self._tables[0]
+
+    @property
+    def Kn(self):
+        if self._tables is None:
+            self._tables = self._kernel_tables()
+        return self._tables[1]
 
     def _kernel_tables(self):
         """peak:248-276: half-offset grid omega = (i + 1/2) d_omega, rotated into the eigenbasis."""
@@ -93,12 +106,20 @@ class PeakProblem:
                 Kn[a:a + len(w)] = kernel_values(self.kernel_type, -w, td.tau, td.beta) @ td.cov   # peak:270-272
         return Kp, Kn
 
-    def make_handle(self, n_chains=1, seed=0, **kw):
-        """SAC(...) + initialize! + calc_Gbar/calc_chi2 + default windows (peak:1482-1507)."""
+    def make_handle(self, n_chains=1, seed=0, device_tables=False, **kw):
+        """SAC(...) + initialize! + calc_Gbar/calc_chi2 + default windows (peak:1482-1507).
+        device_tables: build Kp / Kn on the GPU (sac_build_table) instead of uploading host-built tables."""
         h = SacHandle(self.td.n_tau, self.n_omega, self.n_grid, self.wi_0, self.wi_m, n_chains=n_chains,
                       symm=self.symm, seed=seed, kind=KIND_PEAK, n_peak=self.n_p, fix_edge=self.fix_edge,
                       bosonic=int(self.kernel_type == "bosonic"), **kw)
-        h.upload_problem_peak(self.Kp, self.Kn, self.td.G, self.td.sigma_inv)
+        if device_tables:
+            td = self.td
+            h.build_table(0, self.kernel_type, td.tau, td.beta, td.cov, 0, self.d_omega, offset=0.5, mirror=int(self.symm == 1))
+            if self.sample_neg:
+                h.build_table(1, self.kernel_type, td.tau, td.beta, td.cov, 0, self.d_omega, offset=0.5, negate=1)
+            h.upload_data(td.G, td.sigma_inv)
+        else:
+            h.upload_problem_peak(self.Kp, self.Kn, self.td.G, self.td.sigma_inv)
         h.set_state(self.wi, self.A, np.full(11, self.window / 10))  # peak:1507
         h.init_gbar()
         return h

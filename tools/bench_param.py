@@ -68,6 +68,37 @@ def bench_free2(chains, d_omega=1e-4, n_omega=2000, sweeps=100):
             "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9, "wall_s": dt}
 
 
+def bench_tables(d_omega=1e-5):
+    """Row f1: the 10^6+1-column K table of BASELINE configs[3]'s regime, built on the host (numpy, as the reference's
+    initialize! does) and uploaded, against built on the device (exp + fp64 MFMA basis change)."""
+    import torch
+    from sac_amd.free import FreeProblem
+    td = synthetic_timedata(n_tau=64, seed=SEED)
+    prob = FreeProblem(td, 2000, 0.0, 10.0, d_omega, par=1, kernel_type="bosonic")
+    t0 = time.perf_counter()
+    K = prob.K
+    t_host = time.perf_counter() - t0
+    h = prob.make_handle(n_chains=64, seed=SEED)
+    t0 = time.perf_counter()
+    h.upload_problem(K, td.G, td.sigma_inv)
+    torch.cuda.synchronize()
+    t_up = time.perf_counter() - t0
+    h.build_table(0, "bosonic", td.tau, td.beta, td.cov, prob.wi_0, d_omega)      # warm-up (module load)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        h.build_table(0, "bosonic", td.tau, td.beta, td.cov, prob.wi_0, d_omega)
+        ts.append(time.perf_counter() - t0)
+    t_dev = min(ts)
+    dev = h.get_table(0)
+    err = float((np.abs(dev - K) / (np.abs(K).max(axis=1, keepdims=True))).max())
+    out_bytes = prob.n_grid * 64 * 8
+    flops = 2.0 * prob.n_grid * 64 * 64
+    return {"workload": f"K table {prob.n_grid} x 64 (bosonic), host numpy + upload vs device build", "host_build_s": t_host,
+            "upload_s": t_up, "device_build_s": t_dev, "device_write_GBps": out_bytes / t_dev / 1e9,
+            "mfma_TFLOPs": flops / t_dev / 1e12, "max_rel_diff_vs_host": err}
+
+
 def bench_edge(chains, d_omega=1e-5, n_e=80, steps=40, bins=4):
     """sac/edge single_edge, N_tau=64, N_e=80, three 10^6+1-column tables interleaved (1.5 GB)."""
     from sac_amd.edge import EdgeProblem
@@ -101,6 +132,8 @@ if __name__ == "__main__":
         print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega)), flush=True)
     if a.which in ("peak2",):
         print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega, two_axes=True)), flush=True)
+    if a.which in ("tables",):
+        print(json.dumps(bench_tables(a.d_omega)), flush=True)
     if a.which in ("free2",):
         print(json.dumps(bench_free2(a.chains)), flush=True)
     if a.which in ("edge", "both"):
