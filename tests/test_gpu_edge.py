@@ -17,6 +17,8 @@ CASES = [
     ("double_in_p03", "t3_in", 2e-3, 20, 0, 0.0, 0.3, [(10, 3, 10.0), (6, 2, 2.0)]),
     ("single_continuum_ntau80", "t1_single", 2e-3, 24, 12, 0.3, 0.6, [(10, 3, 10.0), (6, 2, 2.0)]),
     ("single_ne80", "hchain_single", 1e-3, 80, 0, 0.0, 0.5, [(6, 2, 5.0)]),
+    # the limit of the handle: SAC_MAX_N_EDGE = 256 edge deltas (N_tau = 80)
+    ("max_ne256_ntau80", "t1_single", 1e-3, 256, 0, 0.0, 0.5, [(4, 2, 5.0)]),
 ]
 
 

@@ -48,6 +48,10 @@ CASES = [
      1.0, 20, 8),
     ("synth_ntau80_par2_symm", dict(kind="synth", n_tau=80, n_omega=150, par=2, kernel_type="finiteT",
                                     symm=1, omega_m=6.0, d_omega=2e-3), 5.0, 20, 10),
+    # the limits of the handle: SAC_MAX_N_TAU = 128 time points, SAC_MAX_N_OMEGA = 2048 delta functions
+    ("max_ntau128_n2048", dict(kind="synth", n_tau=128, n_omega=2048, omega_m=10.0, d_omega=1e-3), 1.0, 10, 3),
+    ("max_ntau128_n2048_par2", dict(kind="synth", n_tau=128, n_omega=2048, par=2, omega_m=10.0, d_omega=1e-3),
+     1.0, 10, 2),
 ]
 
 
