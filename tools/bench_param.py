@@ -99,10 +99,10 @@ def bench_tables(d_omega=1e-5):
             "mfma_TFLOPs": flops / t_dev / 1e12, "max_rel_diff_vs_host": err}
 
 
-def bench_edge(chains, d_omega=1e-5, n_e=80, steps=40, bins=4):
+def bench_edge(chains, d_omega=1e-5, n_e=80, steps=40, bins=4, n_tau=64):
     """sac/edge single_edge, N_tau=64, N_e=80, three 10^6+1-column tables interleaved (1.5 GB)."""
     from sac_amd.edge import EdgeProblem
-    td = synthetic_timedata(n_tau=64, seed=SEED)
+    td = synthetic_timedata(n_tau=n_tau, seed=SEED)
     prob = EdgeProblem(td, "single_edge", "bosonic", n_e, 0, 0.5, 0.0, 1.0, 0.0, 10.0, d_omega)
     h = prob.make_handle(n_chains=chains, seed=SEED)
     h.run_bins(20, 2, 1.0)
@@ -113,12 +113,12 @@ def bench_edge(chains, d_omega=1e-5, n_e=80, steps=40, bins=4):
     dt = time.perf_counter() - t0
     look = r1["lookups"] - r0["lookups"]
     ms = r1["last_stage_ms"]
-    bytes_alg = look * 5 * 64 * 8            # 3 table columns + K_curr read + K_new write per lookup
-    return {"workload": f"sac/edge single_edge bosonic, N_tau=64, N_e={n_e}, 3 x {prob.kernel.n_grid}-column tables "
-                        f"({3 * prob.kernel.n_grid * 512 / 2**20:.0f} MiB), {chains} chains, Theta=1",
+    bytes_alg = look * 5 * n_tau * 8         # 3 table columns + K_curr read + K_new write per lookup
+    return {"workload": f"sac/edge single_edge bosonic, N_tau={n_tau}, N_e={n_e}, 3 x {prob.kernel.n_grid}-column tables "
+                        f"({3 * prob.kernel.n_grid * 8 * ((n_tau + 7) // 8 * 8) / 2**20:.0f} MiB), {chains} chains, Theta=1",
             "chain_sweeps_per_s": chains * steps * bins / dt, "proposals_per_s": (r1["proposals"] - r0["proposals"]) / dt,
             "lookups_per_s": look / dt, "accepted_per_s": (r1["accepted"] - r0["accepted"]) / dt,
-            "kernel": "edge_stage_kernel<1,false>", "stage_ms": ms, "algorithmic_GBps": bytes_alg / (ms / 1e3) / 1e9,
+            "kernel": f"edge_stage_kernel<{1 if n_tau <= 64 else 2},false>", "stage_ms": ms, "algorithmic_GBps": bytes_alg / (ms / 1e3) / 1e9,
             "hbm_peak_GBps": 8000.0, "frac": bytes_alg / (ms / 1e3) / 1e9 / 8000.0, "violations": r1["violations"], "wall_s": dt}
 
 
@@ -127,6 +127,7 @@ if __name__ == "__main__":
     ap.add_argument("which", nargs="?", default="both")
     ap.add_argument("--chains", type=int, default=4096)
     ap.add_argument("--d-omega", type=float, default=1e-5)
+    ap.add_argument("--n-tau", type=int, default=64)
     a = ap.parse_args()
     if a.which in ("peak", "both"):
         print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega)), flush=True)
@@ -137,4 +138,4 @@ if __name__ == "__main__":
     if a.which in ("free2",):
         print(json.dumps(bench_free2(a.chains)), flush=True)
     if a.which in ("edge", "both"):
-        print(json.dumps(bench_edge(a.chains, d_omega=a.d_omega)), flush=True)
+        print(json.dumps(bench_edge(a.chains, d_omega=a.d_omega, n_tau=a.n_tau)), flush=True)
