@@ -69,6 +69,7 @@ struct Chain {
     WavePriority prio;          // rotated once per group of 64 proposals (wave_ops.h)
     const char *Kb;             // K table, byte addressed
     uint32_t col_bytes;         // bytes per (padded) column
+    uint32_t tab_bytes;         // bytes of one table (< 4 GiB): num_records of the buffer descriptor
     uint32_t *wi;               // LDS
     int lane, n_omega, gmax;
     // what the current move loop draws from and where a delta may land (set per loop):
@@ -94,12 +95,16 @@ struct Chain {
 template <int NTL>
 __device__ __forceinline__ void load_col(const Chain<NTL> &c, int col, double (&out)[NTL])
 {
-    uint32_t lo, hi;
-    asm("s_mul_i32 %0, %1, %2" : "=s"(lo) : "s"(col), "s"(c.col_bytes));
-    asm("s_mul_hi_u32 %0, %1, %2" : "=s"(hi) : "s"(col), "s"(c.col_bytes));
-    const char *base = c.Kb + (((uint64_t)hi << 32) | lo);
+    // buffer load = table descriptor (SGPRs) + scalar byte offset of the column (one s_mul_i32; col is wave-uniform)
+    // + the lane's 32-bit offset: no address arithmetic on the vector ALU.  Tables are below 4 GiB (sac_create checks).
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(c.Kb), 0, (int)c.tab_bytes, 0x00020000);
+    const int soff = col * (int)c.col_bytes;
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) out[t] = *reinterpret_cast<const double *>(base + c.off[t]);
+    for (int t = 0; t < NTL; ++t) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)c.off[t], soff, 0);
+        out[t] = __builtin_bit_cast(double, ((uint64_t)v.y << 32) | v.x);
+    }
 }
 
 // One decoded proposal per lane.  NCOL deltas move: k = index, wold/wnew = relative positions.

@@ -43,6 +43,7 @@ free_stage_kernel(const FreeParams p)
     Chain<NTL> c;
     c.Kb = reinterpret_cast<const char *>(p.K);
     c.col_bytes = (uint32_t)p.ntp * 8u;
+    c.tab_bytes = (uint32_t)((unsigned long long)p.n_grid * (unsigned long long)p.ntp * 8ull);
     c.wi = s_wi[wave];
     c.lane = lane;
     c.prio.init();
@@ -253,6 +254,7 @@ peak_stage_kernel(const PeakParams pp)
     Chain<NTL> c;
     c.Kb = Kp;
     c.col_bytes = (uint32_t)p.ntp * 8u;
+    c.tab_bytes = (uint32_t)((unsigned long long)p.n_grid * (unsigned long long)p.ntp * 8ull);
     c.wi = s_wi_w;
     c.lane = lane;
     c.prio.init();
@@ -448,6 +450,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const P
     Chain<NTL> c;
     c.Kb = reinterpret_cast<const char *>(p.K);
     c.col_bytes = (uint32_t)p.ntp * 8u;
+    c.tab_bytes = (uint32_t)((unsigned long long)p.n_grid * (unsigned long long)p.ntp * 8ull);
     c.wi = p.wi + (size_t)chain * (size_t)p.wi_stride;   // read in place (one pass)
     c.lane = lane;
     c.prio.init();
@@ -662,6 +665,9 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
     if (cfg->n_chains < 1) return fail(SAC_E_INVALID, "sac_create: n_chains=%d", cfg->n_chains);
     if (cfg->n_grid < 1 || cfg->n_grid > (1ll << 30))
         return fail(SAC_E_INVALID, "sac_create: n_grid=%lld outside 1..2^30", (long long)cfg->n_grid);
+    if ((unsigned long long)cfg->n_grid * (unsigned long long)((cfg->n_tau + 7) / 8 * 8) * 8ull >= (1ull << 32))
+        return fail(SAC_E_INVALID, "sac_create: a table of %lld columns x %d time points reaches 4 GiB (columns are addressed "
+                    "with 32-bit byte offsets)", (long long)cfg->n_grid, cfg->n_tau);
     if (cfg->wi_m < cfg->wi_0 || cfg->wi_m - cfg->wi_0 + 1 > cfg->n_grid)
         return fail(SAC_E_INVALID, "sac_create: grid bounds [%lld,%lld] do not fit n_grid=%lld",
                     (long long)cfg->wi_0, (long long)cfg->wi_m, (long long)cfg->n_grid);
