@@ -292,9 +292,7 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                 // compare mask, chi2_new itself comes back to scalar registers only when it is needed
                 const double sum63 = wave_sum_lane63(term);
                 const double ln_u = readlane_f64(d.lnu, j);
-                const unsigned long long am =
-                    __builtin_amdgcn_ballot_w64(metropolis(c.chi2, sum63, c.inv2theta, ln_u));
-                acc = (int)(am >> 63);
+                acc = lane63_true(metropolis(c.chi2, sum63, c.inv2theta, ln_u)) ? 1 : 0;
                 c.n_eval += 1;
                 c.n_cols += 2 * NCOL;
                 if (LOG || acc) chi2_new = readlane_f64(sum63, 63);
@@ -483,7 +481,7 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
                     term = (t == 0) ? e2 : (term + e2);
                 }
                 chi2_new = wave_sum_uniform(term);
-                acc = metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j)) ? 1 : 0;
+                acc = lane63_true(metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j))) ? 1 : 0;
                 c.n_eval += 1;
                 c.n_cols += 4;
                 if (acc) {                                            // free:548-561
@@ -620,7 +618,7 @@ __device__ __forceinline__ int da_move_loop(Chain<NTL> &c, double *A, int n_it)
                     term = (t == 0) ? e2 : (term + e2);
                 }
                 chi2_new = wave_sum_uniform(term);
-                acc = metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j)) ? 1 : 0;
+                acc = lane63_true(metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j))) ? 1 : 0;
                 c.n_eval += 1;
                 c.n_cols += 2;
                 if (acc) {                                            // free:707-718

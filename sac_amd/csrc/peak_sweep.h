@@ -264,7 +264,7 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
                     term = (t == 0) ? e2 : (term + e2);
                 }
                 chi2_new = wave_sum_uniform(term);
-                acc = metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j)) ? 1 : 0;
+                acc = lane63_true(metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j))) ? 1 : 0;
                 c.n_eval += 1;
                 c.n_cols += 2 * NE;
                 if (acc) {

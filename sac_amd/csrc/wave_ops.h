@@ -182,4 +182,13 @@ __device__ __forceinline__ bool metropolis(double chi2, double chi2_new, double 
     return (chi2 - chi2_new) * inv2theta >= ln_u;
 }
 
+// A condition that holds in lane 63 (every lane, when its inputs are wave-uniform), as a scalar: the compare mask's
+// top bit is tested on the scalar unit and branches on it are scalar branches.
+__device__ __forceinline__ bool lane63_true(bool cond)
+{
+    uint32_t hi = (uint32_t)(__builtin_amdgcn_ballot_w64(cond) >> 32);
+    asm("" : "+s"(hi));
+    return (hi >> 31) != 0u;
+}
+
 }  // namespace sacdev
