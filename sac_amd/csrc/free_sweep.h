@@ -212,7 +212,7 @@ __device__ __forceinline__ void increments(const double (&A)[NCOL], const double
 template <int NCOL, int DEPTH, int NTL, bool LOG, bool UA>
 __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it, double window)
 {
-    int accepted = 0;
+    int accepted = 0, n_eval = 0;
     for (int base = 0; base < n_it; base += 64) {
         c.prio.rotate();
         const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
@@ -230,7 +230,6 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
             const int jj = (j < cnt) ? j : cnt - 1;
             const int inb = __builtin_amdgcn_readlane(d.inb, jj);
             is_inb[u] = inb;
-            if (j < cnt) stale &= ~(1ull << j);   // fresh values are read here (not for a clamped re-issue)
 #pragma unroll
             for (int q = 0; q < NCOL; ++q) {
                 const int o = __builtin_amdgcn_readlane(d.wold[q], jj);
@@ -247,8 +246,10 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
             int s_old[NCOL], s_new[NCOL];
 #pragma unroll
             for (int q = 0; q < NCOL; ++q) { s_old[q] = is_old[u][q]; s_new[q] = is_new[u][q]; }
-            const bool was_stale = ((stale >> j) & 1ull) != 0ull;
+            // `stale` holds only proposals whose columns are in flight, so it is almost always zero
+            const bool was_stale = (stale != 0ull) && (((stale >> j) & 1ull) != 0ull);
             if (was_stale) {                 // rare: a delta of this proposal moved meanwhile
+                stale &= ~(1ull << j);
                 inb = __builtin_amdgcn_readlane(d.inb, j);
 #pragma unroll
                 for (int q = 0; q < NCOL; ++q) {
@@ -293,8 +294,7 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                 const double sum63 = wave_sum_lane63(term);
                 const double ln_u = readlane_f64(d.lnu, j);
                 acc = lane63_true(metropolis(c.chi2, sum63, c.inv2theta, ln_u)) ? 1 : 0;
-                c.n_eval += 1;
-                c.n_cols += 2 * NCOL;
+                n_eval += 1;
                 if (LOG || acc) chi2_new = readlane_f64(sum63, 63);
                 if (acc) {                                            // free:310-318
 #pragma unroll
@@ -309,8 +309,6 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                         for (int q = 0; q < NCOL; ++q) c.wi[s_k[q]] = (uint32_t)s_new[q];
                     }
                     accepted += 1;
-                    c.n_acc += 1;
-                    c.n_accmoves += NCOL;
                     // later proposals of this group that use a moved delta: decode again
                     bool hit = false;
 #pragma unroll
@@ -320,7 +318,9 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                     hit = hit && (c.lane > j);
                     const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
                     if (hits != 0ull) {
-                        stale |= hits;
+                        // proposals j+1 .. j+DEPTH-1 have their columns in flight already: those are refetched when
+                        // they are resolved; later ones read the new values when their columns are requested
+                        stale |= hits & ((((1ull << DEPTH) - 2ull)) << j);
                         if (hit) {
 #pragma unroll
                             for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];
@@ -357,6 +357,10 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
             }(std::make_integer_sequence<int, DEPTH>{});
         }
     }
+    c.n_eval += (uint32_t)n_eval;
+    c.n_cols += (uint32_t)n_eval * (uint32_t)(2 * NCOL);
+    c.n_acc += (uint32_t)accepted;
+    c.n_accmoves += (uint32_t)accepted * (uint32_t)NCOL;
     return accepted;
 }
 
