@@ -432,7 +432,6 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
             const int jj = (j < cnt) ? j : cnt - 1;
             const int inb = __builtin_amdgcn_readlane(d.inb, jj);
             is_inb[u] = inb;
-            if (j < cnt) stale &= ~(1ull << j);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int o = __builtin_amdgcn_readlane(d.wold[q], jj);
@@ -449,8 +448,9 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
             int s_old[2], s_new[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) { s_old[q] = is_old[u][q]; s_new[q] = is_new[u][q]; }
-            const bool was_stale = ((stale >> j) & 1ull) != 0ull;
+            const bool was_stale = (stale != 0ull) && (((stale >> j) & 1ull) != 0ull);   // in-flight proposals only
             if (was_stale) {
+                stale &= ~(1ull << j);
                 inb = __builtin_amdgcn_readlane(d.inb, j);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -512,7 +512,7 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
                     hit = hit && (c.lane > j);
                     const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
                     if (hits != 0ull) {
-                        stale |= hits;
+                        stale |= hits & ((((1ull << DEPTH) - 2ull)) << j);   // columns in flight: j+1 .. j+DEPTH-1
                         if (hit) {
 #pragma unroll
                             for (int q = 0; q < 2; ++q) { d.wold[q] = (int)c.wi[d.k[q]]; d.A[q] = A[d.k[q]]; }

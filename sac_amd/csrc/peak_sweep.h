@@ -208,7 +208,6 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
             const int jj = (j < cnt) ? j : cnt - 1;
             const int inb = __builtin_amdgcn_readlane(d.inb, jj);
             is_inb[u] = inb;
-            if (j < cnt) stale &= ~(1ull << j);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const int o = __builtin_amdgcn_readlane(d.wold[e], jj);
@@ -225,8 +224,9 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
             int s_old[NE], s_new[NE];
 #pragma unroll
             for (int e = 0; e < NE; ++e) { s_old[e] = is_old[u][e]; s_new[e] = is_new[u][e]; }
-            const bool was_stale = ((stale >> j) & 1ull) != 0ull;
+            const bool was_stale = (stale != 0ull) && (((stale >> j) & 1ull) != 0ull);   // in-flight proposals only
             if (was_stale) {
+                stale &= ~(1ull << j);
                 inb = __builtin_amdgcn_readlane(d.inb, j);
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
@@ -290,7 +290,7 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
                     hit = hit && (c.lane > j);
                     const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
                     if (hits != 0ull) {
-                        stale |= hits;
+                        stale |= hits & ((((1ull << DEPTH) - 2ull)) << j);   // columns in flight: j+1 .. j+DEPTH-1
                         if (hit) {
 #pragma unroll
                             for (int e = 0; e < NE; ++e) { d.wold[e] = (int)c.wi[d.k[e]]; d.A[e] = A[d.k[e]]; }
