@@ -101,14 +101,10 @@ free_stage_kernel(const FreeParams p)
         constexpr int D1 = (NTL == 1) ? 8 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
         a = move_loop<1, D1, NTL, LOG, UA>(c, 1, n, win[0]);        // free:829-830
         if (lane == 0) acc[0] += (double)a / (double)n;
-#ifndef EXP_NO2
         a = move_loop<2, D2, NTL, LOG, UA>(c, 2, n / 2, win[1]);    // free:832-833
         if (lane == 0) acc[1] += (double)(2 * a) / (double)(n / 2);
-#endif
-#ifndef EXP_NO3
         a = move_loop<3, D3, NTL, LOG, UA>(c, 3, n / 3, 0.0);       // free:835-836
         if (lane == 0) acc[2] += (double)a / (double)(n / 3);
-#endif
         if constexpr (PAR2) {
             double *A = A_g;
             a = aw_move_loop<(NTL == 1) ? 4 : 2, NTL, LOG>(c, A, n / 2, win[3]);   // free:851-852
@@ -118,7 +114,6 @@ free_stage_kernel(const FreeParams p)
             if (lane == 0) acc[4] += (double)a / (double)n;
             renormalise(A, n, p.symm, lane);                        // free:721-725
         }
-#ifndef EXP_NOHIST
         if (p.flags & STAGE_SAMPLE) {
             if (p.hist_mode == SAC_HIST_REFERENCE) {
                 if (p.n_grid <= (1ll << 21))
@@ -132,7 +127,6 @@ free_stage_kernel(const FreeParams p)
             }
             if (lane == 0) *sum_chi2 += c.chi2;                      // free:919
         }
-#endif
         sweep += 1;
     }
 
