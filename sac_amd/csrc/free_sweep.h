@@ -310,18 +310,18 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                     }
                     accepted += 1;
                     // later proposals of this group that use a moved delta: decode again
-                    bool hit = false;
+                    bool same = false;
 #pragma unroll
                     for (int a = 0; a < NCOL; ++a)
 #pragma unroll
-                        for (int b = 0; b < NCOL; ++b) hit = hit || (d.k[a] == s_k[b]);
-                    hit = hit && (c.lane > j);
-                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
+                        for (int b = 0; b < NCOL; ++b) same = same || (d.k[a] == s_k[b]);
+                    // lanes above j only (scalar mask: the common case costs one vector compare)
+                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(same) & ((~0ull << j) << 1);
                     if (hits != 0ull) {
                         // proposals j+1 .. j+DEPTH-1 have their columns in flight already: those are refetched when
                         // they are resolved; later ones read the new values when their columns are requested
                         stale |= hits & ((((1ull << DEPTH) - 2ull)) << j);
-                        if (hit) {
+                        if ((hits >> c.lane) & 1ull) {
 #pragma unroll
                             for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];
                             compute_new<NCOL, UA>(d, c.lo, c.hi);
