@@ -43,3 +43,45 @@ def test_anneal_curve_follows_reference_run(tmp_path):
     log = open(os.path.join(s.output_folder, "log.txt")).read()
     assert "Beginning Main Anneal." in log and "Final Anneal Finished." in log
     assert 0 < theta_opt <= 10.0
+
+
+BDP = os.path.join(os.path.dirname(__file__), "golden", "free_bdp")
+
+
+def _spectrum(path):
+    d = np.loadtxt(path, delimiter=",", skiprows=1)
+    w, S = d[:, 0], d[:, 1]
+    keep = w > 0
+    return w[keep], S[keep]
+
+
+def test_complete_run_reproduces_reference_spectrum(tmp_path):
+    """North-star criterion 2: the final averaged S(omega) and <chi^2>(Theta) agree with the reference within the
+    statistical errors.  tests/golden/free_bdp is the complete run sac/free/out_files/bosonic_delta_peak of the reference
+    (its in_free.in with the full schedule: 150 x 500 sweeps, 5000 sampling sweeps; t.in; anneal.csv; sample.csv; the
+    final spectrum sw000.csv).  The same run here, 64 chains: the Theta ladder must stop at the same point, and the
+    spectrum -- delta peak at omega = 1 plus continuum -- must coincide in position, height, mean and distribution."""
+    s = FreeSAC.from_infile(f"{BDP}/in_free.in", n_chains=64, seed=7)
+    s.G_file = f"{BDP}/t.in"
+    s.output_folder = str(tmp_path / "out")
+    theta_opt = s.run()
+    ref_row = np.loadtxt(f"{BDP}/sample.csv", delimiter=",", skiprows=1, ndmin=2)[0]
+    got_row = np.loadtxt(s.sample_file, delimiter=",", skiprows=1, ndmin=2)[0]
+    # optimal Theta: the same ladder point or a neighbour (f_anneal = 1.1)
+    assert abs(np.log(theta_opt / ref_row[2])) < np.log(1.1) * 1.5
+    assert abs(got_row[4] / ref_row[4] - 1) < 0.03                  # <chi^2>/N_tau at the sampling temperature
+    assert got_row[3] < ref_row[3] * 1.02                            # chi2_min/N_tau (ours: minimum over 64 chains)
+    ref = np.loadtxt(f"{BDP}/anneal.csv", delimiter=",", skiprows=1)
+    got = np.loadtxt(s.anneal_file, delimiter=",", skiprows=1)
+    n = min(len(ref), len(got))
+    assert abs(len(got) - len(ref)) <= 8                             # the stop rule fires within a few ladder points
+    assert np.abs(np.log(got[:n, 3] / ref[:n, 3])).max() < 0.08
+    wr, Sr = _spectrum(f"{BDP}/sw000.csv")
+    wg, Sg = _spectrum(os.path.join(s.output_folder, "sw000.csv"))
+    assert abs(wg[np.argmax(Sg)] - wr[np.argmax(Sr)]) <= 0.0101      # the delta peak, to two output bins (0.005 each)
+    assert abs(Sg.max() / Sr.max() - 1) < 0.10
+    mean_r, mean_g = (Sr * wr).sum() / Sr.sum(), (Sg * wg).sum() / Sg.sum()
+    assert abs(mean_g / mean_r - 1) < 0.005
+    grid = np.linspace(0.0, 2.5, 501)
+    cdf = lambda w, S: np.interp(grid, w, np.cumsum(S) / S.sum())    # noqa: E731
+    assert np.abs(cdf(wg, Sg) - cdf(wr, Sr)).max() < 0.03

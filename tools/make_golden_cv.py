@@ -38,6 +38,7 @@ def main():
 if __name__ == "__main__":
     main()
     peak_fixture()
+    free_spectrum_fixture()
 
 
 def peak_fixture():
@@ -54,4 +55,20 @@ def peak_fixture():
     with open(f"{out}/in_peak.in") as f:          # keep the six parameter rows, drop the commentary
         rows = f.readlines()[:6]
     with open(f"{out}/in_peak.in", "w") as f:
+        f.writelines(rows)
+
+
+def free_spectrum_fixture():
+    """Committed complete reference run of sac_free.jl with its final spectrum (statistical oracle for S(omega)):
+    sac/free/out_files/bosonic_delta_peak/{t.in,in_free.in,anneal.csv,sample.csv,sw000.csv} -> tests/golden/free_bdp/
+    (data only; in_free.in cut to its six parameter rows)."""
+    src = "/root/reference/sac/free/out_files/bosonic_delta_peak"
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "free_bdp")
+    os.makedirs(out, exist_ok=True)
+    for name in ("t.in", "in_free.in", "anneal.csv", "sample.csv", "sw000.csv"):
+        shutil.copyfile(f"{src}/{name}", f"{out}/{name}")
+    os.system(f"chmod -R u+w {out}")
+    with open(f"{out}/in_free.in") as f:
+        rows = f.readlines()[:6]
+    with open(f"{out}/in_free.in", "w") as f:
         f.writelines(rows)
