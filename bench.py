@@ -28,7 +28,7 @@ SEED = 12345
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def cpu_baseline(prob, windows, wi, seconds=12.0):
+def cpu_baseline(prob, windows, wi, theta=THETA, seconds=12.0):
     """The oracle (CPU port of the reference loops, -O2 -march=native, 1 thread) on the same
     problem, same Theta, same tuned windows: sample sweeps for ~`seconds` s."""
     from oracle import oracle as ora
@@ -36,12 +36,12 @@ def cpu_baseline(prob, windows, wi, seconds=12.0):
     o.set_state(wi, prob.A, windows)
     o.init_gbar()
     o.use_philox(SEED, 1 << 30)
-    o.sample(5, THETA)
+    o.sample(5, theta)
     c0 = o.counters()
     t0 = time.perf_counter()
     sweeps = 0
     while time.perf_counter() - t0 < seconds:
-        o.sample(50, THETA)
+        o.sample(50, theta)
         sweeps += 50
     dt = time.perf_counter() - t0
     c1 = o.counters()
@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--sweeps-per-step", type=int, default=SWEEPS_PER_STEP)
     ap.add_argument("--d-omega", type=float, default=D_OMEGA)
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = the library's default")
+    ap.add_argument("--theta", type=float, default=THETA, help="sampling temperature (headline: 1.0)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -96,14 +97,15 @@ def main():
     # chains are block-partitioned over ranks; the Philox key holds the global chain id
     h = prob.make_handle(n_chains=args.chains, seed=SEED, chain_offset=rank * args.chains,
                          device=local_rank, sweeps_per_launch=args.sweeps_per_launch)
-    h.adjust_windows(250, THETA)             # equilibrate + tune the windows (untimed; 10 x 25 sweeps)
+    theta = args.theta
+    h.adjust_windows(250, theta)             # equilibrate + tune the windows (untimed; 10 x 25 sweeps)
 
     hist_dev = torch.zeros(prob.n_grid, dtype=torch.float64, device="cuda")
     stat_dev = torch.zeros(8, dtype=torch.float64, device="cuda")
     min_dev = torch.zeros(1, dtype=torch.float64, device="cuda")
 
     def step():
-        h.sample(args.sweeps_per_step, THETA)
+        h.sample(args.sweeps_per_step, theta)
         if world > 1:
             # per-stage merge (the only collective on the path): histogram + chi^2 statistics
             h.histogram_sum_to_device(hist_dev.data_ptr())
@@ -168,10 +170,10 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: ranks share a GPU, gloo merge -- not a result)",
             "config": {"workload": "sac/free bosonic, N_tau=64, 2000 delta-functions, "
-                                   f"{prob.n_grid}-point omega grid, {args.chains} chains per MI355X, Theta=1 "
+                                   f"{prob.n_grid}-point omega grid, {args.chains} chains per MI355X, Theta={theta:g} "
                                    "(BASELINE.json configs[1])",
                        "chains_per_gpu": args.chains, "sweeps_per_step": args.sweeps_per_step,
-                       "theta": THETA, "parallelism": f"chains sharded over {world} GPU(s), "
+                       "theta": theta, "parallelism": f"chains sharded over {world} GPU(s), "
                                                       "one RCCL all-reduce per stage"},
             "sweeps_per_s": sweeps / dt_max, "proposals_per_s": props / dt_max,
             "acceptance": {"evaluated_frac": evald / props, "accepted_moves_per_proposal": moves / props},
@@ -185,7 +187,7 @@ def main():
         if world == 1 and not args.no_cpu:
             from oracle import oracle as ora
             ora.lib()
-            cb = cpu_baseline(prob, win0, wi0)
+            cb = cpu_baseline(prob, win0, wi0, theta)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_core"] = out["value"] / cb["value"]
         print(json.dumps(out))
