@@ -55,6 +55,7 @@ struct EdgeParams {
     double A_c, A_r, d0, w_floor[2], w_m, dwg, inv_dwg, c[2];
     uint32_t seed_lo, seed_hi, chain_offset;
     int n_sweeps, flags;
+    int prio_shift;             // WavePriority clock shift for this launch (host: prio_shift_for)
     double steps_in_bin, inv2theta;
 };
 

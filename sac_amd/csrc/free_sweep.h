@@ -58,6 +58,7 @@ struct FreeParams {
     int hist_copies, hist_exclusive, hist_mode;
     int n_sweeps, flags, par, symm;
     int log_chain;
+    int prio_shift;             // WavePriority clock shift for this launch (host: prio_shift_for)
 };
 
 constexpr int WAVES_PER_BLOCK = 4;

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
     EdgeChain<NTL> c;
     c.p = &hp;
     c.lane = lane;
-    c.prio.init();
+    c.prio.init(p.prio_shift);
     c.chain = chain;
     {
         double *d = reinterpret_cast<double *>(s_dyn);
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) edge_init_kernel(const EdgeParams p)
     EdgeChain<NTL> c;
     c.p = &p;
     c.lane = lane;
-    c.prio.init();
+    c.prio.init(p.prio_shift);
     c.n_cols = 0;
     const size_t cs = (size_t)chain * 2u * (size_t)S;
 #pragma unroll
@@ -444,6 +444,7 @@ struct sac_edge {
     bool table_built[2] = {false, false};   // sac_edge_build_tables
     int64_t last_steps = 0, last_bins = 0;
     double last_stage_ms = 0.0;
+    double ms_per_sweep = 0.0;     // measured stage time per sweep (priority rotation period)
 };
 
 static int use_device(sac_edge *h)
@@ -842,6 +843,7 @@ extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, dou
             if (chunk > h->sweeps_per_launch) chunk = h->sweeps_per_launch;
             p.n_sweeps = (int)chunk;
             p.flags = (done == 0 ? EDGE_BIN_START : 0) | (done + chunk >= steps ? EDGE_BIN_END : 0);
+            p.prio_shift = prio_shift_for(h->ms_per_sweep * (double)chunk);
             if ((rc = launch_stage(h, p))) return rc;
             done += chunk;
         }
@@ -851,6 +853,7 @@ extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, dou
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->last_stage_ms = ms;
+    if (steps * bins > 0 && ms > 0.f) h->ms_per_sweep = (double)ms / (double)(steps * bins);
     h->last_steps = steps;
     h->last_bins = bins;
     return SAC_OK;

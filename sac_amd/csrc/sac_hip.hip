@@ -46,7 +46,7 @@ free_stage_kernel(const FreeParams p)
     c.tab_bytes = (uint32_t)((unsigned long long)p.n_grid * (unsigned long long)p.ntp * 8ull);
     c.wi = s_wi[wave];
     c.lane = lane;
-    c.prio.init();
+    c.prio.init(p.prio_shift);
     c.n_omega = p.n_omega;
     c.gmax = p.gmax;
     c.k_first = 0; c.k_count = p.n_omega; c.lo = 0; c.hi = p.gmax;
@@ -251,7 +251,7 @@ peak_stage_kernel(const PeakParams pp)
     c.tab_bytes = (uint32_t)((unsigned long long)p.n_grid * (unsigned long long)p.ntp * 8ull);
     c.wi = s_wi_w;
     c.lane = lane;
-    c.prio.init();
+    c.prio.init(p.prio_shift);
     c.n_omega = n;
     c.gmax = pp.wim;
     c.inv2theta = p.inv2theta;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) peak_init_kernel(const P
     c.tab_bytes = (uint32_t)((unsigned long long)p.n_grid * (unsigned long long)p.ntp * 8ull);
     c.wi = p.wi + (size_t)chain * (size_t)p.wi_stride;   // read in place (one pass)
     c.lane = lane;
-    c.prio.init();
+    c.prio.init(p.prio_shift);
 #pragma unroll
     for (int t = 0; t < NTL; ++t) {
         const int j = lane + 64 * t;
@@ -623,6 +623,7 @@ struct sac_handle {
     int last_stage = 0;            // 0 none, 1 adjust_windows, 2 sample
     int64_t last_steps = 0;
     double last_stage_ms = 0.0, last_kernel_ms = 0.0;
+    double ms_per_sweep = 0.0;     // measured kernel time per sweep of the last stage (priority rotation period)
     int64_t last_launches = 0;
 };
 
@@ -1046,6 +1047,7 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
         const bool last = (done + chunk >= n_sweeps);
         p.n_sweeps = (int)chunk;
         p.flags = flags_all | (first ? flags_first : 0) | (last ? flags_last : 0);
+        p.prio_shift = prio_shift_for(h->ms_per_sweep * (double)chunk);
         const size_t li = (size_t)h->last_launches;
         if (h->kev.size() <= li) {
             hipEvent_t a, b;
@@ -1113,6 +1115,7 @@ static int stage_end(sac_handle *h, int kind, int64_t steps)
         kms += k;
     }
     h->last_kernel_ms = kms;
+    if (steps > 0 && kms > 0.0) h->ms_per_sweep = kms / (double)steps;
     h->last_stage = kind;
     h->last_steps = steps;
     return SAC_OK;
@@ -1203,6 +1206,7 @@ static int run_peak_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int fl
         const bool last = (done + chunk >= n_sweeps);
         pp.f.n_sweeps = (int)chunk;
         pp.f.flags = flags_all | (first ? flags_first : 0) | (last ? flags_last : 0);
+        pp.f.prio_shift = prio_shift_for(h->ms_per_sweep * (double)chunk);
         const size_t li = (size_t)h->last_launches;
         if (h->kev.size() <= li) {
             hipEvent_t a, b;

@@ -73,19 +73,26 @@ __device__ __forceinline__ double wave_sum_uniform(double v)
 // The instruction arbiter serves the waves of a SIMD oldest first: of four resident chains the one in
 // wave slot 0 ran 1.7 x as fast as the one in slot 3 (79 M against 134 M cycles per 25-sweep launch,
 // identical from launch to launch), and a launch lasts as long as its slowest chain.  Each wave therefore
-// walks through the four user priorities (s_setprio), one step per call, starting from its slot number:
-// every chain spends the same share of its proposals at each level and they finish together.
+// walks through the four user priorities (s_setprio), starting from its slot number: every chain spends the
+// same share of its time at each level and they finish together.
 struct WavePriority {
-    int slot;
-    uint32_t tick;
-    __device__ __forceinline__ void init()
+    int slot, shift;
+    unsigned long long t;       // clock read at the previous call (used one call later: never waited for)
+    __device__ __forceinline__ void init(int shift_)
     {
         slot = (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 0xFu);   // HW_ID.wave_id
-        tick = 0;
+        shift = shift_;
+        t = __builtin_amdgcn_s_memtime();
     }
+    // The level follows the clock (one step every 2^shift cycles), so the waves of a SIMD change together and
+    // hold four different levels at all times, whatever their progress.  Long steps run fastest (2^22 cycles gave
+    // +5 % over 2^14) as long as a launch sees several full rotations: the host picks the shift from the
+    // measured duration of the previous launches (prio_shift_for()).
     __device__ __forceinline__ void rotate()
     {
-        switch ((slot + (int)tick++) & 3) {            // s_setprio takes an immediate
+        const int level = (slot + (int)(uint32_t)(t >> shift)) & 3;
+        t = __builtin_amdgcn_s_memtime();
+        switch (level) {                               // s_setprio takes an immediate
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -192,3 +199,14 @@ __device__ __forceinline__ bool lane63_true(bool cond)
 }
 
 }  // namespace sacdev
+
+// Host side: clock shift of the priority rotation for a launch expected to last `launch_ms` (0 = unknown):
+// about eight full rotations (32 steps) per launch, a step between 2^12 and 2^22 cycles (2.4 GHz).
+static inline int prio_shift_for(double launch_ms)
+{
+    if (!(launch_ms > 0.0)) return 17;
+    const double step_cycles = launch_ms * 2.4e6 / 32.0;
+    int sh = 12;
+    while (sh < 22 && (double)(1ull << (sh + 1)) <= step_cycles) ++sh;
+    return sh;
+}
