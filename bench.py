@@ -98,7 +98,8 @@ def main():
     h = prob.make_handle(n_chains=args.chains, seed=SEED, chain_offset=rank * args.chains,
                          device=local_rank, sweeps_per_launch=args.sweeps_per_launch)
     theta = args.theta
-    h.adjust_windows(250, theta)             # equilibrate + tune the windows (untimed; 10 x 25 sweeps)
+    h.adjust_windows(1000, theta)            # equilibrate + tune the windows (untimed; 10 rounds of 100 sweeps, so that
+                                             # every launch of the run has the size of the timed ones)
 
     hist_dev = torch.zeros(prob.n_grid, dtype=torch.float64, device="cuda")
     stat_dev = torch.zeros(8, dtype=torch.float64, device="cuda")
@@ -159,7 +160,10 @@ def main():
             t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             w = t["workload"]
             if (w["n_tau"], w["n_omega"], w["n_grid"], w["chains"]) == (N_TAU, N_OMEGA, prob.n_grid, args.chains):
-                traffic = (2.0 * t["fetch_size_kb_median"] + t["write_size_kb_median"]) * 1024.0
+                # per launch of THIS run: the profiled launch scaled by the sweeps a launch ran here
+                sweeps_per_launch_here = sweeps_r0 / args.chains / max(launches, 1)
+                traffic = ((2.0 * t["fetch_size_kb_median"] + t["write_size_kb_median"]) * 1024.0
+                           * sweeps_per_launch_here / w["sweeps_per_launch"])
         except (OSError, KeyError, ValueError):
             pass
         wi0, _, win0 = h.get_state(0)

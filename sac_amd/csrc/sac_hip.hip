@@ -592,7 +592,7 @@ struct sac_handle {
     int wi_stride = 0;
     int hist_copies = 1;
     bool hist_exclusive = false;
-    int sweeps_per_launch = 25;
+    int sweeps_per_launch = 100;
     double *dK = nullptr, *dG = nullptr, *dSinv = nullptr, *dA = nullptr, *dGbar = nullptr;
     double *dHist = nullptr;
     uint32_t *dWi = nullptr;

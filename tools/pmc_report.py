@@ -20,10 +20,10 @@ SRC = _pos[0] if _pos else os.path.join(ROOT, "gpurun_out", "pmc_f")
 
 # workload -> (description, chain-sweeps of the launch looked at, kernel, proposals per sweep or None, which dispatch)
 UNITS = {
-    "free": ("bench.py --steps 3 --warmup 1 --no-cpu: launch = 25 sweeps x 4096 chains", 25 * 4096, "free_stage_kernel", 3666, "median"),
+    "free": ("bench.py --steps 3 --warmup 1 --no-cpu: launch = 100 sweeps x 4096 chains (the median dispatch)", 100 * 4096, "free_stage_kernel", 3666, "median"),
     "edge": ("tools/bench_param.py edge: launch = 40 sweeps x 4096 chains (N_e=80)", 40 * 4096, "edge_stage_kernel", None, "median"),
-    "peak": ("tools/bench_param.py peak: the 25-sweep launches of the timed sample stage = the largest dispatches "
-             "(the median dispatch is a 10-sweep adjust_windows launch); 1000+1 deltas, 4096 chains", 25 * 4096,
+    "peak": ("tools/bench_param.py peak: the 100-sweep launch of the timed sample stage = the largest dispatch "
+             "(the median dispatch is a 10-sweep adjust_windows launch); 1000+1 deltas, 4096 chains", 100 * 4096,
              "peak_stage_kernel", None, "max"),
 }
 
@@ -85,7 +85,7 @@ def main():
                                    "profiles/r01_g_pmc_summary.txt), for bench.py's roofline.traffic. bytes = (2*FETCH_SIZE + "
                                    "WRITE_SIZE)*1024: FETCH_SIZE counts half the bytes on gfx950, calibrated on this access pattern in "
                                    "profiles/r01_gather_probe.txt.",
-                       "workload": {"n_tau": 64, "n_omega": 2000, "n_grid": 100001, "chains": 4096, "sweeps_per_launch": 25},
+                       "workload": {"n_tau": 64, "n_omega": 2000, "n_grid": 100001, "chains": 4096, "sweeps_per_launch": 100},
                        "fetch_size_kb_median": use["FETCH_SIZE"], "write_size_kb_median": use["WRITE_SIZE"],
                        "source": "profiles/r01_g_pmc_summary.txt"},
                       open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=2)
