@@ -8,11 +8,17 @@ every chain (proposals, K-column gathers, chi^2, Metropolis, S(omega) histogram,
 for N>1 by the per-stage RCCL all-reduce that merges histogram and chi^2 statistics.
 
     python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torch.distributed environment the parent starts the N ranks itself (a child
+`python -m torch.distributed.run ... bench.py`, before anything here touches the GPU) and relays rank 0's line;
+under `torch.distributed.run` (RANK / WORLD_SIZE set) it is one rank.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,16 +32,28 @@ SWEEPS_PER_STEP = 400
 THETA = 1.0
 SEED = 12345
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
+CLOCK_GHZ = 2.4           # peak engine clock
+# a wave64 VALU instruction occupies its SIMD for one "quad-cycle" (4 clocks: 16 lanes per clock); SQ_ACTIVE_INST_VALU
+# counts those.  Ceiling of VALU issue on the whole chip, in G quad-cycles per second:
+VALU_ISSUE_PEAK = N_SIMD * CLOCK_GHZ / 4.0
 
 
-def cpu_baseline(prob, windows, wi, theta=THETA, seconds=12.0):
-    """The oracle (CPU port of the reference loops, -O2 -march=native, 1 thread) on the same
-    problem, same Theta, same tuned windows: sample sweeps for ~`seconds` s."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (CPU port of the reference loops), P concurrent single-thread processes
+# ------------------------------------------------------------------------------------------------
+
+def cpu_worker(state_dir, idx, seconds):
+    """One single-thread process of the CPU baseline: the oracle's `sample` sweeps on the bench problem for
+    ~`seconds` s (own Philox stream).  Prints one JSON line."""
     from oracle import oracle as ora
-    o = ora.OracleFree(prob.K, prob.td.G, prob.td.sigma_inv, prob.n_omega, prob.wi_0, prob.wi_m)
-    o.set_state(wi, prob.A, windows)
+    K = np.load(os.path.join(state_dir, "K.npy"), mmap_mode="r")
+    st = np.load(os.path.join(state_dir, "state.npz"))
+    o = ora.OracleFree(np.ascontiguousarray(K), st["G"], st["sigma_inv"], int(st["n_omega"]), int(st["wi_0"]), int(st["wi_m"]))
+    o.set_state(st["wi"], st["A"], st["windows"])
     o.init_gbar()
-    o.use_philox(SEED, 1 << 30)
+    o.use_philox(SEED, (1 << 30) + idx)
+    theta = float(st["theta"])
     o.sample(5, theta)
     c0 = o.counters()
     t0 = time.perf_counter()
@@ -45,12 +63,104 @@ def cpu_baseline(prob, windows, wi, theta=THETA, seconds=12.0):
         sweeps += 50
     dt = time.perf_counter() - t0
     c1 = o.counters()
-    return {"value": (c1[3] - c0[3]) / dt, "unit": "accepted delta-moves/s", "cores": 1, "kind": "port",
-            "sample": f"{sweeps} sample sweeps of one chain ({dt:.1f} s) on the bench problem at the tuned windows",
-            "sweeps_per_s": sweeps / dt, "proposals_per_s": (c1[0] - c0[0]) / dt}
+    print(json.dumps({"moves_per_s": (c1[3] - c0[3]) / dt, "sweeps_per_s": sweeps / dt,
+                      "proposals_per_s": (c1[0] - c0[0]) / dt, "sweeps": sweeps, "seconds": dt}))
+
+
+def cpu_baseline(prob, windows, wi, theta=THETA, seconds=10.0, procs=None):
+    """P independent single-thread oracle processes (-O2 -march=native) running concurrently on the box's host
+    cores, each one chain of the same problem at the same Theta and tuned windows; aggregate rate."""
+    if procs is None:
+        procs = min(16, len(os.sched_getaffinity(0)))      # the GPU box gives one GPU's job 16 host cores
+    with tempfile.TemporaryDirectory(prefix="sac_cpu_") as d:
+        np.save(os.path.join(d, "K.npy"), prob.K)
+        np.savez(os.path.join(d, "state.npz"), G=prob.td.G, sigma_inv=prob.td.sigma_inv, n_omega=prob.n_omega,
+                 wi_0=prob.wi_0, wi_m=prob.wi_m, wi=wi, A=prob.A, windows=windows, theta=theta)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", d, str(i), str(seconds)],
+                               stdout=subprocess.PIPE, env=env, text=True) for i in range(procs)]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
+    tot = {k: sum(o[k] for o in outs) for k in ("moves_per_s", "sweeps_per_s", "proposals_per_s", "sweeps")}
+    return {"value": tot["moves_per_s"], "unit": "accepted delta-moves/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} concurrent single-thread processes of the CPU port (oracle/), one chain each, "
+                      f"{tot['sweeps']} sample sweeps in total ({max(o['seconds'] for o in outs):.1f} s) on the bench problem "
+                      "at the tuned windows",
+            "sweeps_per_s": tot["sweeps_per_s"], "proposals_per_s": tot["proposals_per_s"],
+            "per_core_value": tot["moves_per_s"] / procs}
+
+
+# ------------------------------------------------------------------------------------------------
+# HBM-resident regime, driver-timed in the same run (extra keys; the headline table is cache resident)
+# ------------------------------------------------------------------------------------------------
+
+def hbm_regime(device, chains, theta=THETA):
+    """Two short `sample` stages each of (a) sac/free on a 10^6+1-column and on a 4*10^6+1-column table (488 MiB /
+    1.9 GiB: beyond L2 + the 256 MB Infinity Cache) and (b) BASELINE configs[3]'s sac/peak shape (10^6+1 columns);
+    tables built on the device.  algorithmic bytes = gathered K columns x N_tau x 8 B over the HIP-event kernel time."""
+    from sac_amd.free import FreeProblem
+    from sac_amd.peak import PeakProblem
+    from sac_amd.synth import synthetic_timedata
+    td = synthetic_timedata(n_tau=N_TAU, seed=SEED)
+    out = []
+
+    def run(name, h, stats, sweeps):
+        h.adjust_windows(200, theta)
+        h.sample(sweeps, theta)
+        s0 = stats()
+        kms, nl = 0.0, 0
+        for _ in range(2):
+            h.sample(sweeps, theta)
+            s = stats()
+            kms += s.last_kernel_ms
+            nl += s.last_kernel_launches
+        cols = s.columns_gathered - s0.columns_gathered
+        gbps = cols * N_TAU * 8 / (kms / 1e3) / 1e9
+        out.append({"workload": name, "bound": "hbm", "launches": nl, "avg_launch_ms": kms / nl,
+                    "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                    "chain_sweeps_per_s": (s.sweeps - s0.sweeps) / (kms / 1e3),
+                    "accepted_moves_per_s": (s.accepted_moves - s0.accepted_moves) / (kms / 1e3)})
+        h.close()
+
+    for d_omega in (1e-5, 2.5e-6):
+        prob = FreeProblem(td, N_OMEGA, 0.0, OMEGA_M, d_omega, par=1, kernel_type="bosonic")
+        h = prob.make_handle(n_chains=chains, seed=SEED, device=device, device_tables=True)
+        run(f"sac/free bosonic, N_tau=64, 2000 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
+            f"{chains} chains", h, h.stats, 100)
+    prob = PeakProblem(td, 1000, 1, 0.5, OMEGA_M, 1e-5, kernel_type="bosonic")
+    h = prob.make_handle(n_chains=chains, seed=SEED, device=device, device_tables=True)
+    run(f"sac/peak bosonic, N_tau=64, 1000+1 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
+        f"{chains} chains (BASELINE.json configs[3])", h, h.peak_stats, 100)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` as typed: N fresh rank processes under torch.distributed.run, started before this
+    process has touched torch or the GPU; rank 0's JSON line is relayed.  (SAC_BENCH_REHEARSE=1: the ranks share the
+    GPUs that exist and merge over gloo -- development only.)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.exit(p.returncode if p.returncode else (0 if line else 1))
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2], int(sys.argv[3]), float(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -61,7 +171,12 @@ def main():
     ap.add_argument("--sweeps-per-launch", type=int, default=0, help="0 = the library's default")
     ap.add_argument("--theta", type=float, default=THETA, help="sampling temperature (headline: 1.0)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip the extra HBM-resident runs")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline (0 = the box's core share)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
@@ -69,7 +184,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # SAC_BENCH_REHEARSE=1 (development only, never a reported number): ranks share the GPUs that exist and merge
     # over gloo, to walk the N>1 code path on a one-GPU box; the driver's runs use RCCL, one GPU per rank.
     rehearse = os.environ.get("SAC_BENCH_REHEARSE") == "1"
@@ -148,24 +263,47 @@ def main():
     dt_max, moves, props, sweeps, cols, evald = (float(x) for x in local.cpu())
 
     if rank == 0:
-        # roofline of the dominant kernel (free_stage_kernel), this rank, measured with HIP events
-        # on the library's stream around every launch of the timed region.
+        # Roofline of the dominant kernel (free_stage_kernel), this rank, measured with HIP events on the library's
+        # stream around every launch of the timed region.  The 51 MB table of this configuration is L2 / Infinity-Cache
+        # resident (TCC hit 2/3), so HBM does not bind it: the binding resource is VALU issue on the SIMDs (PMC:
+        # SQ_ACTIVE_INST_VALU, profiles/traffic.json).  bound/achieved/peak/frac are stated against that ceiling; the
+        # algorithmic gather rate and the counter-based HBM fraction are extra keys.
         cols_r0 = s1.columns_gathered - s0.columns_gathered
         sweeps_r0 = s1.sweeps - s0.sweeps
+        n_l = max(launches, 1)
         alg_bytes = cols_r0 * N_TAU * 8 + sweeps_r0 * N_OMEGA * 16   # K columns + histogram RMW
-        per_launch_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = alg_bytes / max(launches, 1) / per_launch_s / 1e9
-        traffic = None
-        try:    # PMC-derived traffic of the same launch shape, collected in separate rocprofv3 passes
-            t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            w = t["workload"]
+        per_launch_s = kernel_ms / 1e3 / n_l
+        alg_gbps = alg_bytes / n_l / per_launch_s / 1e9
+        traffic = valu_qc = pmc = None
+        try:    # PMC counters of the same launch shape, collected in separate rocprofv3 passes
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            w = pmc["workload"]
             if (w["n_tau"], w["n_omega"], w["n_grid"], w["chains"]) == (N_TAU, N_OMEGA, prob.n_grid, args.chains):
                 # per launch of THIS run: the profiled launch scaled by the sweeps a launch ran here
-                sweeps_per_launch_here = sweeps_r0 / args.chains / max(launches, 1)
-                traffic = ((2.0 * t["fetch_size_kb_median"] + t["write_size_kb_median"]) * 1024.0
-                           * sweeps_per_launch_here / w["sweeps_per_launch"])
+                scale = sweeps_r0 / args.chains / n_l / w["sweeps_per_launch"]
+                traffic = (2.0 * pmc["fetch_size_kb_median"] + pmc["write_size_kb_median"]) * 1024.0 * scale
+                valu_qc = pmc["valu_active_quad_cycles_median"] * scale
         except (OSError, KeyError, ValueError):
             pass
+        if valu_qc is not None:
+            ach = valu_qc / per_launch_s / 1e9
+            roof = {"bound": "valu-issue", "achieved": ach, "peak": VALU_ISSUE_PEAK,
+                    "unit": "G wave64 VALU issue quad-cycles/s (peak = 1024 SIMDs x 2.4 GHz / 4)",
+                    "frac": ach / VALU_ISSUE_PEAK,
+                    "valu_insts_per_proposal": pmc["valu_insts_median"] * scale / ((s1.proposals - s0.proposals) / n_l),
+                    "salu_insts_per_proposal": pmc["salu_insts_median"] * scale / ((s1.proposals - s0.proposals) / n_l)}
+        else:
+            roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_ISSUE_PEAK,
+                    "unit": "G wave64 VALU issue quad-cycles/s", "frac": None}
+        roof.update({"traffic": traffic,
+                     "traffic_note": "bytes per launch beyond L2, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json",
+                     "hbm_frac": None if traffic is None else traffic / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_GBps": alg_gbps, "algorithmic_over_hbm_peak": alg_gbps / HBM_PEAK_GBS,
+                     "note": "table is cache resident: the algorithmic gather rate exceeds the HBM peak and is not a "
+                             "roofline fraction; see hbm_regime for the HBM-bound shapes",
+                     "kernel": "free_stage_kernel<1,false,true,false>", "launches": launches,
+                     "avg_launch_ms": per_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes / n_l,
+                     "pmc_source": None if pmc is None else pmc.get("source")})
         wi0, _, win0 = h.get_state(0)
         out = {
             "metric": "accepted delta-moves/sec (whole node) at N_tau=64, N_delta=2000",
@@ -181,21 +319,18 @@ def main():
                                                       "one RCCL all-reduce per stage"},
             "sweeps_per_s": sweeps / dt_max, "proposals_per_s": props / dt_max,
             "acceptance": {"evaluated_frac": evald / props, "accepted_moves_per_proposal": moves / props},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch beyond L2, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json",
-                         "kernel": "free_stage_kernel<1,false,true,false>", "launches": launches,
-                         "avg_launch_ms": per_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1)},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu:
-            from oracle import oracle as ora
-            ora.lib()
-            cb = cpu_baseline(prob, win0, wi0, theta)
-            out["cpu_baseline"] = cb
-            out["speedup_vs_cpu_core"] = out["value"] / cb["value"]
-        print(json.dumps(out))
     h.close()
+    if rank == 0:
+        if world == 1 and not args.no_hbm_regime and not rehearse:
+            out["hbm_regime"] = hbm_regime(local_rank, args.chains, theta)
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(prob, win0, wi0, theta, procs=args.cpu_procs or None)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+            out["speedup_note"] = f"one MI355X against {cb['cores']} host cores running the CPU port concurrently"
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

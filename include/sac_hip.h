@@ -122,7 +122,9 @@ int sac_destroy(sac_handle_t *h);
 int sac_upload_problem(sac_handle_t *h, const double *K, const double *G, const double *sigma_inv);
 
 /* omega_i_array / A_array / update_windows of one chain (chain = -1: all chains).  NULL = keep.
- * free:215, 1218, 1254. */
+ * free:215, 1218, 1254.  Writing positions or amplitudes (and sac_upload_problem*, sac_upload_data,
+ * sac_build_table) invalidates Gbar / chi2: the stages return SAC_E_STATE until sac_init_gbar or sac_set_gbar
+ * has run again (the free kernels never rebuild Gbar from the positions, free:876). */
 int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, const double *A,
                   const double *windows);
 int sac_get_state(sac_handle_t *h, int32_t chain, int64_t *wi, double *A, double *windows);
@@ -145,7 +147,8 @@ int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6, double *ac
 /* self.sampled_spec (free:59,918,924): mean over chains of the per-chain sweep average, n_grid doubles. */
 int sac_get_histogram(sac_handle_t *h, double *out);
 /* Same histogram as the un-normalised sum over this handle's chains, written to DEVICE memory
- * (e.g. a tensor handed to an RCCL all-reduce); *steps_times_chains receives the divisor. */
+ * (e.g. a tensor handed to an RCCL all-reduce); *steps_times_chains receives the divisor.
+ * dst_device must be device memory on the handle's GPU (checked: SAC_E_INVALID otherwise). */
 int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, double *steps_times_chains);
 
 /* ---- K table built on the device ------------------------------------

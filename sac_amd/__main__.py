@@ -5,6 +5,10 @@ cross_val.jl:514-531): run from a directory holding in_free.in / in_peak.in / in
     python -m sac_amd peak  [A_0 N_p] [--chains N]
     python -m sac_amd edge  [A_c A_r p] [--chains N]
     python -m sac_amd cv free|peak|edge REP a|b [--chains N]
+    python -m torch.distributed.run --nproc-per-node G -m sac_amd free|peak|edge ...
+        (the run's chains sharded over G GPUs, --chains per GPU: one RCCL all-reduce per stage merges the statistics
+         and every rank takes the same schedule decisions; only rank 0 writes files.  The reference's fan-out is one
+         Julia process per parameter point, run_cv.sh:5-9 / qsub_files/edge/submit.sh:25-51)
     python -m torch.distributed.run --nproc-per-node G -m sac_amd cv-all REP_FIRST REP_LAST [free,peak,edge]
         (replicas x halves x parameterisations round-robin over the G GPUs; in-files in the working directory)
 """
@@ -19,20 +23,40 @@ def main(argv=None):
     ap.add_argument("--chains", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
+                                                       "(nccl = RCCL; gloo for rehearsals on shared GPUs)")
     a = ap.parse_args(argv)
     kw = dict(n_chains=a.chains, seed=a.seed, device=a.device)
-    if a.program == "free":
-        from .free import FreeSAC
-        return FreeSAC.from_infile("in_free.in", **kw).run("in_free.in")
-    if a.program == "peak":
-        from .peak import PeakSAC
-        A_0 = float(a.args[0]) if len(a.args) > 0 else None
-        N_p = int(a.args[1]) if len(a.args) > 1 else None
-        return PeakSAC.from_infile("in_peak.in", A_0_in=A_0, N_p_in=N_p, **kw).run("in_peak.in")
-    if a.program == "edge":
-        from .edge import EdgeSAC
-        v = [float(x) for x in a.args[:3]] + [None] * (3 - len(a.args[:3]))
-        return EdgeSAC.from_infile("in_edge.in", A_c_in=v[0], A_r_in=v[1], p_in=v[2], **kw).run("in_edge.in")
+    if a.program in ("free", "peak", "edge"):
+        import os
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:                                   # one process per GPU, chains sharded over the ranks
+            import torch
+            import torch.distributed as dist
+            from .dist import Comm
+            kw["device"] = int(os.environ.get("LOCAL_RANK", str(a.device))) % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(kw["device"])
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", kw["device"]))
+                kw["comm"] = Comm(device=torch.device("cuda", kw["device"]))
+            else:
+                dist.init_process_group(a.backend)
+                kw["comm"] = Comm()
+        try:
+            if a.program == "free":
+                from .free import FreeSAC
+                return FreeSAC.from_infile("in_free.in", **kw).run("in_free.in")
+            if a.program == "peak":
+                from .peak import PeakSAC
+                A_0 = float(a.args[0]) if len(a.args) > 0 else None
+                N_p = int(a.args[1]) if len(a.args) > 1 else None
+                return PeakSAC.from_infile("in_peak.in", A_0_in=A_0, N_p_in=N_p, **kw).run("in_peak.in")
+            from .edge import EdgeSAC
+            v = [float(x) for x in a.args[:3]] + [None] * (3 - len(a.args[:3]))
+            return EdgeSAC.from_infile("in_edge.in", A_c_in=v[0], A_r_in=v[1], p_in=v[2], **kw).run("in_edge.in")
+        finally:
+            if world > 1:
+                dist.destroy_process_group()
     if a.program == "cv-all":
         import os
         from .cross_val import cv_units, run_cv_partition

@@ -32,8 +32,8 @@ def free_cv(rep, ab, in_file="in_free.in", **kw):
 
 
 def _free_cv_run(s, in_file=None):
-    os.makedirs(s.output_folder, exist_ok=True)
     if s.is_root:
+        os.makedirs(s.output_folder, exist_ok=True)
         if in_file and os.path.exists(in_file):
             shutil.copyfile(in_file, s.output_folder + "/in_free.in")   # cv:32-33
         if s.timedata is None:
@@ -73,10 +73,12 @@ def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, **kw):
     if symm_tag:
         root = root[: -len(symm_tag)]
     s.output_folder = root + "/%03i%s/peak" % (rep, ab) + symm_tag + tail
-    os.makedirs(s.output_folder, exist_ok=True)
+    if s.is_root:
+        os.makedirs(s.output_folder, exist_ok=True)
     s.tol = 1e-6
     gsac = s.output_folder + "/GSAC.csv"
-    open(gsac, "w").close()
+    if s.is_root:
+        open(gsac, "w").close()
     s.init_outfiles()
     s.write_log("Beginning Initialization.", "w")
     s.initialize()
@@ -92,7 +94,12 @@ def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, **kw):
         g = np.zeros(s.td.n_tau)
         for c in range(s.n_chains):
             g += s.h.get_gbar(c)[0][: s.td.n_tau]
-        _append_gsac(gsac, theta, s.td.cov, g / s.n_chains)
+        n = float(s.n_chains)
+        if s.comm is not None:                                      # chain mean over all ranks, as edge_cv does
+            tot = s.comm.sum_vector(np.concatenate([g, [n]]))
+            g, n = tot[:-1], tot[-1]
+        if s.is_root:
+            _append_gsac(gsac, theta, s.td.cov, g / n)
 
     s.run_anneal(s.theta_0, on_stage=dump)
     return s
@@ -110,7 +117,8 @@ def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, **kw):
     if s.mode in ("double_edge_in", "double_edge_out"):
         out += "/Ar_%.3f" % s.A_r
     s.output_folder = out
-    os.makedirs(out, exist_ok=True)
+    if s.is_root:
+        os.makedirs(out, exist_ok=True)
     gsac = out + "/GSAC.csv"
     if s.is_root:
         open(gsac, "w").close()

@@ -116,7 +116,7 @@ free_stage_kernel(const FreeParams p)
         }
         if (p.flags & STAGE_SAMPLE) {
             if (p.hist_mode == SAC_HIST_REFERENCE) {
-                if (p.n_grid <= (1ll << 21))
+                if (p.n_grid < (1ll << 21))
                     hist_reference<uint32_t, 32>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
                                                  p.hist_exclusive, lane);
                 else
@@ -764,6 +764,7 @@ extern "C" int sac_upload_problem(sac_handle_t *h, const double *K, const double
     HIP_TRY(hipMemcpy(h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
     h->problem = true;
+    h->gbar_set = false;            // Gbar / chi2 of the old problem: sac_init_gbar (or sac_set_gbar) must follow
     return SAC_OK;
 }
 
@@ -781,6 +782,7 @@ extern "C" int sac_upload_data(sac_handle_t *h, const double *G, const double *s
     HIP_TRY(hipMemcpy(h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
     h->problem = true;
+    h->gbar_set = false;
     return SAC_OK;
 }
 
@@ -865,6 +867,7 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
         HIP_TRY(hipMemcpy(h->dWi + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(uint32_t),
                           hipMemcpyHostToDevice));
         h->state_set = true;
+        h->gbar_set = false;        // the kernels never rebuild Gbar from the positions (free:876 assigns a dead local)
     }
     if (A) {
         bool uni = true;
@@ -885,6 +888,7 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
         } else if (!(h->uniform_A && uni && A[0] == h->A_uniform)) {
             h->uniform_A = false;
         }
+        h->gbar_set = false;
     }
     if (windows && h->peak) {
         std::vector<PeakScalars> sc((size_t)count);
@@ -1657,6 +1661,15 @@ extern "C" int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, d
     if (h->last_stage != 2) return fail(SAC_E_STATE, "sac_get_histogram_sum_device: no sample stage has run");
     int rc;
     if ((rc = use_device(h))) return rc;
+    // a kernel writes through dst_device: refuse anything that is not device memory of this handle's GPU
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dst_device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(SAC_E_INVALID, "sac_get_histogram_sum_device: dst_device is not a device pointer (pageable host memory?)");
+    }
+    if (attr.type != hipMemoryTypeDevice || attr.device != h->cfg.device)
+        return fail(SAC_E_INVALID, "sac_get_histogram_sum_device: dst_device must be device memory on GPU %d (memory type %d on "
+                    "device %d)", h->cfg.device, (int)attr.type, attr.device);
     const long long ng = h->cfg.n_grid;
     hipLaunchKernelGGL(hist_sum_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, h->stream,
                        (const double *)h->dHist, ng, h->hist_copies, (double *)dst_device);

@@ -99,7 +99,12 @@ class Comm:
         return hist_sum / d
 
     def merge_histogram(self, handle):
-        """Histogram of a SacHandle merged over ranks (device-side sum, RCCL all-reduce)."""
-        buf = torch.empty(handle.n_grid, dtype=torch.float64, device=self.device)
+        """Histogram of a SacHandle merged over ranks (device-side sum, RCCL all-reduce).  The replica sum is
+        always written on the handle's own GPU (sac_get_histogram_sum_device takes a DEVICE pointer); with a
+        host-side group (gloo) it is staged through host memory for the all-reduce."""
+        gpu = torch.device("cuda", int(handle.cfg.device))
+        buf = torch.empty(handle.n_grid, dtype=torch.float64, device=gpu)
         divisor = handle.histogram_sum_to_device(buf.data_ptr())
+        if self.device != gpu:
+            buf = buf.to(self.device)
         return self.merge_histogram_sum(buf, divisor).cpu().numpy()

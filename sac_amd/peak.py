@@ -433,11 +433,12 @@ class PeakSAC:
         import os
         import shutil
         from .free import jl_float
-        os.makedirs(self.output_folder, exist_ok=True)
-        if in_file and os.path.exists(in_file):
-            shutil.copyfile(in_file, self.output_folder + "/in_peak.in")
-        if self.timedata is None and os.path.exists(self.G_file):
-            shutil.copyfile(self.G_file, self.output_folder + "/t.in")
+        if self.is_root:
+            os.makedirs(self.output_folder, exist_ok=True)
+            if in_file and os.path.exists(in_file):
+                shutil.copyfile(in_file, self.output_folder + "/in_peak.in")
+            if self.timedata is None and os.path.exists(self.G_file):
+                shutil.copyfile(self.G_file, self.output_folder + "/t.in")
         self.init_outfiles()
         self.write_log("Beginning Initialization.", "w")
         self.initialize()

@@ -13,7 +13,7 @@ P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VAL
 P3="FETCH_SIZE GRBM_GUI_ACTIVE"
 P4="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 P2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
-FREE="$R/bench.py --steps 3 --warmup 1 --no-cpu"
+FREE="$R/bench.py --steps 3 --warmup 1 --no-cpu --no-hbm-regime"
 EDGE="$R/tools/bench_param.py edge"
 PEAK="$R/tools/bench_param.py peak"
 run free_p1 "$P1" $FREE && run free_p3 "$P3" $FREE && run free_p4 "$P4" $FREE && \

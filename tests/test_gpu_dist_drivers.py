@@ -1,4 +1,4 @@
-"""N>1 path of the peak and edge drivers on the GPU box: two processes (gloo for the merge; both use the one
+"""N>1 path of the free, peak and edge drivers on the GPU box: two processes (gloo for the merge; both use the one
 MI355X of the box), chains sharded by chain_offset = rank * n_chains.  Every rank must end a stage with the
 statistics of the single-process run over all chains (a chain's trajectory depends only on its global id)."""
 import os
@@ -46,12 +46,34 @@ def _peak(comm, n_chains, folder):
     return out
 
 
+def _free(comm, n_chains, folder):
+    """FreeSAC + Comm: window tuning, a sample stage, the merged histogram (Comm.merge_histogram: replica sum on the
+    handle's GPU, staged through host for gloo) and write_spec (free:959-1019)."""
+    from sac_amd.free import FreeSAC
+    from sac_amd.tin import read_tin
+    td = read_tin(f"{GOLD}/cv/t_001a.in")
+    s = FreeSAC(1, 60, 0.0, 4.0, 2e-3, 0.02, 5.0, 1.1, 1.05, 0.5, 0.5, 5, 20, 20, "", folder, 0, "bosonic",
+                n_chains=n_chains, seed=33, timedata=td, comm=comm)
+    s.init_outfiles()
+    s.initialize()
+    s.adjust_windows(20, 5.0)
+    s.sample(10, 5.0)
+    spec = s.sampled_spec()
+    coarse = s.write_spec(1)
+    out = dict(sampled_chi2=s.sampled_chi2, chi2_min=s.chi2_min, accept_rates=np.array(s.accept_rates),
+               windows=np.array(s.update_windows), hist=spec, gbar=s.mean_gbar())
+    if coarse is not None:
+        out["spec"] = coarse
+    return out
+
+
 def _worker(rank, world, port, base, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sac_amd.dist import Comm
     comm = Comm()
+    out[("free", rank)] = _free(comm, 4, f"{base}/free2")
     out[("edge", rank)] = _edge(comm, 4, f"{base}/edge2")
     out[("peak", rank)] = _peak(comm, 4, f"{base}/peak2")
     dist.destroy_process_group()
@@ -64,10 +86,16 @@ def test_two_rank_drivers_equal_single_process(tmp_path):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    f1 = _free(None, 8, str(tmp_path / "free1"))
+    assert f1["hist"].sum() > 0
     e1 = _edge(None, 8, str(tmp_path / "edge1"))
     p1 = _peak(None, 8, str(tmp_path / "peak1"))
     for rank in (0, 1):
-        e2, p2 = out[("edge", rank)], out[("peak", rank)]
+        e2, p2, f2 = out[("edge", rank)], out[("peak", rank)], out[("free", rank)]
+        for k, v in f1.items():
+            if k in f2:
+                np.testing.assert_allclose(f2[k], v, rtol=1e-11, atol=1e-13, err_msg=f"free {k}")
+        assert ("spec" in f2) == (rank == 0)
         for k, v in e1.items():
             np.testing.assert_allclose(e2[k], v, rtol=1e-11, atol=1e-13, err_msg=f"edge {k}")
         for k, v in p1.items():
@@ -78,3 +106,4 @@ def test_two_rank_drivers_equal_single_process(tmp_path):
     b = open(tmp_path / "edge1" / "anneal.csv").read().split("\n")
     assert len(a) == len(b) == 3 and a[0] == b[0]
     assert os.path.exists(tmp_path / "edge2" / "sw001_1.dat") and os.path.exists(tmp_path / "peak2" / "sw001.csv")
+    assert open(tmp_path / "free2" / "sw001.csv").read() == open(tmp_path / "free1" / "sw001.csv").read()

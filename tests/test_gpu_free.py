@@ -193,6 +193,31 @@ def test_error_paths_do_not_exit():
     h.close()
 
 
+def test_new_positions_invalidate_gbar():
+    """Writing positions / amplitudes / a problem on an initialised handle leaves Gbar and chi2 stale (the free
+    kernels never rebuild them, free:876): the stages refuse to run (SAC_E_STATE) until sac_init_gbar has run again."""
+    prob = helpers.problem_golden_bosonic(n_omega=60, omega_m=3.0, d_omega=1e-3)
+    h = prob.make_handle(n_chains=2, seed=1)
+    h.sample(3, 1.0)
+    wi, A, win = h.get_state(0)
+    h.set_state(windows=win)                     # windows only: Gbar stays valid
+    h.sample(3, 1.0)
+    for write in (lambda: h.set_state(wi=wi, chain=1), lambda: h.set_state(A=A),
+                  lambda: h.upload_problem(prob.K, prob.td.G, prob.td.sigma_inv)):
+        write()
+        with pytest.raises(SacError, match="sac_init_gbar"):
+            h.sample(3, 1.0)
+        with pytest.raises(SacError, match="sac_init_gbar"):
+            h.adjust_windows(10, 1.0)
+        h.init_gbar()
+        h.sample(3, 1.0)
+    # the replica sum is written by a kernel: a host pointer is refused, not written through
+    host = np.zeros(prob.n_grid)
+    with pytest.raises(SacError, match="device"):
+        h.histogram_sum_to_device(host.ctypes.data)
+    h.close()
+
+
 def test_replay_of_an_explicit_proposal_stream():
     """sac_replay: a foreign proposal stream (indices, new positions, accept draws) evaluated by
     the library agrees with a direct fp64 evaluation to <= 1e-12 relative per move (the north-star tolerance),

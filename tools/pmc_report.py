@@ -87,6 +87,8 @@ def main():
                                    "profiles/r01_gather_probe.txt.",
                        "workload": {"n_tau": 64, "n_omega": 2000, "n_grid": 100001, "chains": 4096, "sweeps_per_launch": 100},
                        "fetch_size_kb_median": use["FETCH_SIZE"], "write_size_kb_median": use["WRITE_SIZE"],
+                       "valu_active_quad_cycles_median": use["SQ_ACTIVE_INST_VALU"], "valu_insts_median": use["SQ_INSTS_VALU"],
+                       "salu_insts_median": use["SQ_INSTS_SALU"],
                        "source": "profiles/r01_g_pmc_summary.txt"},
                       open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=2)
 
