@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -586,6 +587,33 @@ int sac_internal_fail(int code, const char *msg)
                         __FILE__, __LINE__);                                              \
     } while (0)
 
+// ---- scratch of sac_build_table_noalloc ---------------------------------------------------------
+// Staging area for tau[n_tau] and U[n_tau][n_tau] (what sac_build_table puts into two hipMalloc'ed buffers): one
+// file-scope device array per GPU, 132 KB, held until the process ends.  Host code never uses the array's name as
+// an address: sac_create resolves it once per device (hipGetSymbolAddress with that device current) and every
+// later use goes through the resolved pointer.
+constexpr size_t SCRATCH_DOUBLES = (size_t)SAC_MAX_N_TAU + (size_t)SAC_MAX_N_TAU * SAC_MAX_N_TAU;
+static __device__ __align__(256) double scratch[SCRATCH_DOUBLES];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static double *g_scratch_ptr[MAX_DEVICES] = {};
+
+// The calling thread's current device must be `device`.
+static int resolve_scratch(int device, double **out)
+{
+    if (device < 0 || device >= MAX_DEVICES) return SAC_E_INVALID;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        double *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return SAC_E_HIP;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return SAC_OK;
+}
+
 struct sac_handle {
     sac_config_t cfg{};
     int ntp = 0;
@@ -601,6 +629,7 @@ struct sac_handle {
     unsigned long long *dLogLen = nullptr;
     long long log_cap = 0;
     int log_chain = -1;
+    double *scratch = nullptr;     // this GPU's copy of the file-scope `scratch` array (resolved by sac_create)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;   // reusable per-launch event pairs
@@ -693,6 +722,10 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
 
     int rc = use_device(h);
     if (rc) { delete h; return rc; }
+    if ((rc = resolve_scratch(cfg->device, &h->scratch))) {
+        delete h;
+        return fail(rc, "sac_create: hipGetSymbolAddress(scratch) failed on device %d", cfg->device);
+    }
     const size_t nc = (size_t)cfg->n_chains;
 #define ALLOC(ptr, bytes)                                                           \
     do {                                                                            \
@@ -816,6 +849,43 @@ extern "C" int sac_build_table(sac_handle_t *h, int32_t which, const sac_table_s
     (void)hipFree(d_tau);
     (void)hipFree(d_U);
     if (e != hipSuccess) return fail(SAC_E_HIP, "sac_build_table: %s", hipGetErrorString(e));
+    h->table_built[which] = true;
+    h->gbar_set = false;
+    return SAC_OK;
+}
+
+// sac_build_table for callers that cannot allocate: tau and U are staged in this GPU's `scratch` array instead of
+// two hipMalloc'ed buffers.  No hipMalloc / hipFree / allocating library call on this path.  The scratch array is
+// shared by every handle on the GPU and keeps the last call's contents: calls that overlap on one GPU race.
+extern "C" int sac_build_table_noalloc(sac_handle_t *h, int32_t which, const sac_table_spec_t *spec, const double *tau,
+                                       const double *U)
+{
+    if (!h || !spec || !tau || !U) return fail(SAC_E_INVALID, "sac_build_table_noalloc: null argument");
+    if (which < 0 || which > 1 || (which == 1 && !h->dKn))
+        return fail(SAC_E_INVALID, "sac_build_table_noalloc: table %d does not exist on this handle", which);
+    if (spec->kernel_type < 0 || spec->kernel_type > 2)
+        return fail(SAC_E_INVALID, "sac_build_table_noalloc: Invalid Kernel type.");   // free:195
+    if (!(spec->d_omega > 0) || !std::isfinite(spec->beta) || !std::isfinite(spec->offset))
+        return fail(SAC_E_INVALID, "sac_build_table_noalloc: d_omega=%g beta=%g offset=%g", spec->d_omega, spec->beta, spec->offset);
+    const size_t nt = (size_t)h->cfg.n_tau;
+    if (nt > (size_t)SAC_MAX_N_TAU || nt + nt * nt > SCRATCH_DOUBLES)
+        return fail(SAC_E_INVALID, "sac_build_table_noalloc: n_tau=%zu exceeds the scratch array (n_tau <= %d, %zu bytes)", nt,
+                    SAC_MAX_N_TAU, SCRATCH_DOUBLES * sizeof(double));
+    if (!h->scratch) return fail(SAC_E_STATE, "sac_build_table_noalloc: scratch array not resolved on device %d", h->cfg.device);
+    int rc = use_device(h);
+    if (rc) return rc;
+    for (size_t j = 0; j < nt; ++j)
+        if (!std::isfinite(tau[j])) return fail(SAC_E_INVALID, "sac_build_table_noalloc: non-finite tau[%zu]", j);
+    double *d_tau = h->scratch, *d_U = h->scratch + SAC_MAX_N_TAU;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice));
+    TableSpec sp;
+    sp.kernel_type = spec->kernel_type; sp.n_tau = (int)nt; sp.mirror = spec->mirror; sp.negate = spec->negate;
+    sp.i_first = spec->i_first; sp.offset = spec->offset; sp.d_omega = spec->d_omega; sp.beta = spec->beta;
+    sp.n_grid = h->cfg.n_grid; sp.ld = h->ntp; sp.n_cols = h->ntp;
+    HIP_TRY(launch_table_build(h->stream, sp, d_tau, d_U, which == 0 ? h->dK : h->dKn));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->table_built[which] = true;
     h->gbar_set = false;
     return SAC_OK;

@@ -19,7 +19,7 @@ EXPORTS = [
     "sac_edge_init_gbar", "sac_edge_run_bins", "sac_edge_get_results", "sac_edge_get_accept_rates",
     "sac_edge_get_histogram", "sac_edge_get_avg", "sac_edge_get_gbar", "sac_edge_set_move_log",
     "sac_edge_get_move_log",
-    "sac_build_table", "sac_get_table", "sac_upload_data",
+    "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
 ]
 
@@ -138,6 +138,7 @@ def load_library():
     L.sac_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_get_chain_chi2.argtypes = [vp, dp, dp]
     L.sac_build_table.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
+    L.sac_build_table_noalloc.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_get_table.argtypes = [vp, C.c_int32, dp]
     L.sac_upload_data.argtypes = [vp, dp, dp]
     L.sac_edge_build_tables.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
@@ -266,14 +267,16 @@ class SacHandle:
                     edge_mean=o[4:6].copy())
 
     # ---- SAC_KIND_PEAK ----------------------------------------------------------------------
-    def build_table(self, which, kernel_type, tau, beta, U, i_first, d_omega, offset=0.0, mirror=0, negate=0):
-        """K table built on the device (sac_build_table): which = 0 K / Kp, 1 Kn; U = the reference's `cov`."""
+    def build_table(self, which, kernel_type, tau, beta, U, i_first, d_omega, offset=0.0, mirror=0, negate=0, noalloc=False):
+        """K table built on the device (sac_build_table): which = 0 K / Kp, 1 Kn; U = the reference's `cov`.
+        noalloc: the entry point that stages tau / U in the library's file-scope device array (no hipMalloc)."""
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         U = np.ascontiguousarray(U, dtype=np.float64)
         if tau.shape != (self.n_tau,) or U.shape != (self.n_tau, self.n_tau):
             raise SacError("tau must have n_tau entries and U n_tau x n_tau")
         sp = _table_spec(kernel_type, i_first, d_omega, beta, offset, mirror, negate)
-        self._check(self.L.sac_build_table(self.h, int(which), C.byref(sp), _dp(tau), _dp(U)))
+        fn = self.L.sac_build_table_noalloc if noalloc else self.L.sac_build_table
+        self._check(fn(self.h, int(which), C.byref(sp), _dp(tau), _dp(U)))
 
     def get_table(self, which=0):
         out = np.empty((self.n_grid, self.n_tau))

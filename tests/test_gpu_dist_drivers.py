@@ -106,4 +106,5 @@ def test_two_rank_drivers_equal_single_process(tmp_path):
     b = open(tmp_path / "edge1" / "anneal.csv").read().split("\n")
     assert len(a) == len(b) == 3 and a[0] == b[0]
     assert os.path.exists(tmp_path / "edge2" / "sw001_1.dat") and os.path.exists(tmp_path / "peak2" / "sw001.csv")
-    assert open(tmp_path / "free2" / "sw001.csv").read() == open(tmp_path / "free1" / "sw001.csv").read()
+    two, one = (np.loadtxt(tmp_path / d / "sw001.csv", delimiter=",", skiprows=1) for d in ("free2", "free1"))
+    np.testing.assert_allclose(two, one, rtol=1e-11, atol=0)         # the merge adds the ranks' sums in another order
