@@ -209,6 +209,16 @@ int sac_copy_chain(sac_handle_t *h, int32_t src, int32_t dst);
 /* chi2 and chi2_min of every chain of the handle (n_chains doubles each; either may be NULL). */
 int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min);
 
+/* Scheduling knob (no counterpart in the reference, which runs one chain on one core): how many chains of a
+ * SAC_KIND_FREE handle share one wavefront -- 1, 2 or 4; 0 = the library chooses.  Every chain's trajectory and
+ * every result is the same, bit for bit, for every value; only the mapping onto the wave changes
+ * (free_sweep_packed.h: the chi^2 tree and the wave-uniform bookkeeping are paid once per step for all chains of the
+ * wave).  Shapes the packed kernel does not serve (par = 2 or 3, n_chains not a multiple, N_tau above
+ * 4 slots per lane of the chain) fall back to fewer chains per wave; sac_get_chains_per_wave reports what the last
+ * sweep launch used. */
+int sac_set_chains_per_wave(sac_handle_t *h, int32_t chains_per_wave);
+int sac_get_chains_per_wave(sac_handle_t *h, int32_t *last_used);
+
 /* Parity / debug entry (no counterpart in the reference): evaluates an explicit proposal stream
  * on one chain of the free parameterisation (par = 1 or 3) -- what the reference's move loops do once the
  * indices, the new positions (in bounds) and the accept uniform are drawn (free:296-320, 354-380, 437-470).

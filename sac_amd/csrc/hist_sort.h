@@ -90,7 +90,9 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyT (&key)[EPL], int lane)
 //   A / A_uniform amplitudes
 //   exclusive  the replica belongs to this chain alone: plain read-modify-write (bit exact);
 //              otherwise fp64 hardware atomics.
-template <typename KeyT, int EPL>
+// TAG only separates instantiations: an out-of-line function inherits the register budget of the kernels that call
+// it, so kernels with different occupancy targets must not share one copy.
+template <typename KeyT, int EPL, int TAG = 0>
 __device__ __attribute__((noinline)) void hist_reference(const uint32_t *wi, int n, const double *A,
                                                double A_uniform, int uniform_A, double *hist,
                                                int exclusive, int lane)

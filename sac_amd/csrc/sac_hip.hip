@@ -16,6 +16,7 @@
 #include "../../include/sac_hip.h"
 #include "free_sweep.h"
 #include "hist_sort.h"
+#include "free_sweep_packed.h"
 #include "peak_sweep.h"
 #include "table_build.h"
 
@@ -621,6 +622,8 @@ struct sac_handle {
     int hist_copies = 1;
     bool hist_exclusive = false;
     int sweeps_per_launch = 100;
+    int chains_per_wave = 0;       // sac_set_chains_per_wave: 0 = the library chooses
+    int last_chains_per_wave = 1;  // what the last sweep launch used
     double *dK = nullptr, *dG = nullptr, *dSinv = nullptr, *dA = nullptr, *dGbar = nullptr;
     double *dHist = nullptr;
     uint32_t *dWi = nullptr;
@@ -1103,6 +1106,27 @@ extern "C" int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, 
     return SAC_OK;
 }
 
+// Chains per wave of the next free sweep launch: the caller's choice (sac_set_chains_per_wave) when the shape allows
+// it, else the library's.  Several chains share a wave only with equal fixed amplitudes (par = 1), a
+// chain count that fills whole waves, N_tau <= 64 and <= 4 slots x the chain's lanes, and positions that fit the CU's LDS.
+static int packed_chains_per_wave(const sac_handle *h)
+{
+    auto fits = [&](int c) {
+        if (c == 1) return true;
+        if (h->cfg.n_chains % c != 0) return false;
+        if (h->cfg.n_tau > 64 || 4 * (64 / c) < h->cfg.n_tau) return false;
+        return (size_t)WAVES_PER_BLOCK * packed_lds_bytes_per_wave(c, h->wi_stride) <= 160u * 1024u;
+    };
+    int want = h->chains_per_wave;
+    // automatic: two chains per wave once N_tau <= 32 leaves half of every wave idle and there are enough chains to
+    // fill the chip's 4096 wave slots that way (measured, profiles/r02_packed_scan.jsonl: 1.49 x at N_tau = 22,
+    // 1.47 x at N_tau = 32 with 8192 chains; 0.96 x with 4096 chains, and 0.93 x for 32 < N_tau <= 64 where the
+    // packed kernel holds two waves per SIMD)
+    if (want == 0) want = (h->cfg.n_tau <= 32 && h->cfg.n_chains >= 6144) ? 2 : 1;
+    while (want > 1 && !fits(want)) want /= 2;
+    return want;
+}
+
 // Launches `n_sweeps` sweeps in chunks; flags_first apply to the first chunk only (zeroing),
 // flags_last to the last chunk only (retune), flags_all to every chunk.
 static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_all, int flags_first,
@@ -1133,6 +1157,43 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
         const bool par2 = (h->cfg.par == 2);
         const bool ua = h->uniform_A && !par2;
         const int wpb = WAVES_PER_BLOCK;
+        const int cpw = ua ? packed_chains_per_wave(h) : 1;
+        h->last_chains_per_wave = cpw;
+        if (cpw > 1) {
+            // several chains per wave (free_sweep_packed.h): same chains, other mapping onto the wave
+            const int lpc = 64 / cpw;
+            const int T = (lpc >= h->cfg.n_tau) ? 1 : (2 * lpc >= h->cfg.n_tau) ? 2 : 4;
+            const int waves = h->cfg.n_chains / cpw;
+            const dim3 pgrid((unsigned)((waves + wpb - 1) / wpb)), pblock(64 * wpb);
+            const size_t lds = (size_t)wpb * packed_lds_bytes_per_wave(cpw, h->wi_stride);
+#define SAC_PK1(C_, T_, L_)                                                                                     \
+    do {                                                                                                        \
+        if (lds > 48 * 1024)                                                                                    \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&free_stage_packed_kernel<C_, T_, L_>),  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+        hipLaunchKernelGGL((free_stage_packed_kernel<C_, T_, L_>), pgrid, pblock, lds, h->stream, p);           \
+    } while (0)
+#define SAC_PK(C_, T_)                                                                                          \
+    do {                                                                                                        \
+        if (log) SAC_PK1(C_, T_, true);                                                                         \
+        else SAC_PK1(C_, T_, false);                                                                            \
+    } while (0)
+            switch (cpw * 8 + T) {
+            case 2 * 8 + 1: SAC_PK(2, 1); break;
+            case 2 * 8 + 2: SAC_PK(2, 2); break;
+            case 4 * 8 + 1: SAC_PK(4, 1); break;
+            case 4 * 8 + 2: SAC_PK(4, 2); break;
+            default: SAC_PK(4, 4); break;
+            }
+#undef SAC_PK
+#undef SAC_PK1
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
+            h->last_launches += 1;
+            done += chunk;
+            first = false;
+            continue;
+        }
         const dim3 grid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), block(64 * wpb);
         const int variant = (par2 ? 8 : 0) | (h->cfg.n_tau <= 64 ? 0 : 4) | (log ? 2 : 0) | (ua ? 1 : 0);
 #define SAC_LAUNCH(NTL_, LOG_, UA_, P2_) \
@@ -1192,6 +1253,23 @@ static int stage_end(sac_handle *h, int kind, int64_t steps)
     if (steps > 0 && kms > 0.0) h->ms_per_sweep = kms / (double)steps;
     h->last_stage = kind;
     h->last_steps = steps;
+    return SAC_OK;
+}
+
+extern "C" int sac_set_chains_per_wave(sac_handle_t *h, int32_t chains_per_wave)
+{
+    if (!h) return fail(SAC_E_INVALID, "sac_set_chains_per_wave: null handle");
+    if (h->peak) return fail(SAC_E_INVALID, "sac_set_chains_per_wave: free parameterisation only");
+    if (chains_per_wave != 0 && chains_per_wave != 1 && chains_per_wave != 2 && chains_per_wave != 4)
+        return fail(SAC_E_INVALID, "sac_set_chains_per_wave: %d (0 = automatic, 1, 2 or 4)", chains_per_wave);
+    h->chains_per_wave = chains_per_wave;
+    return SAC_OK;
+}
+
+extern "C" int sac_get_chains_per_wave(sac_handle_t *h, int32_t *last_used)
+{
+    if (!h || !last_used) return fail(SAC_E_INVALID, "sac_get_chains_per_wave: null argument");
+    *last_used = h->last_chains_per_wave;
     return SAC_OK;
 }
 

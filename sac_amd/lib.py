@@ -21,6 +21,7 @@ EXPORTS = [
     "sac_edge_get_move_log",
     "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
+    "sac_set_chains_per_wave", "sac_get_chains_per_wave",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -141,6 +142,8 @@ def load_library():
     L.sac_build_table_noalloc.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_get_table.argtypes = [vp, C.c_int32, dp]
     L.sac_upload_data.argtypes = [vp, dp, dp]
+    L.sac_set_chains_per_wave.argtypes = [vp, C.c_int32]
+    L.sac_get_chains_per_wave.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sac_edge_build_tables.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_edge_upload_data.argtypes = [vp, dp, dp]
     L.sac_edge_get_tables.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -247,6 +250,16 @@ class SacHandle:
     def set_gbar(self, gbar, chi2, chi2_min, chain=-1):
         gbar = np.ascontiguousarray(gbar, dtype=np.float64)
         self._check(self.L.sac_set_gbar(self.h, chain, _dp(gbar), chi2, chi2_min))
+
+    def set_chains_per_wave(self, chains_per_wave):
+        """0 = the library chooses; 1, 2, 4 = Markov chains sharing one wavefront (same chains, other schedule)."""
+        self._check(self.L.sac_set_chains_per_wave(self.h, int(chains_per_wave)))
+
+    def chains_per_wave(self):
+        """Chains per wavefront the last sweep launch ran with."""
+        out = C.c_int32(0)
+        self._check(self.L.sac_get_chains_per_wave(self.h, C.byref(out)))
+        return out.value
 
     def adjust_windows(self, steps, theta):
         self._check(self.L.sac_adjust_windows(self.h, int(steps), float(theta)))
