@@ -96,12 +96,31 @@ __device__ __forceinline__ unsigned long long expand_chain_bits(unsigned long lo
     }
 }
 
+// a where the lane's bit of `mask` is set, else b: the 64-bit scalar IS the lane mask of one v_cndmask per dword
+// (the compiler's own ((mask >> lane) & 1) costs three vector instructions before the select)
+__device__ __forceinline__ uint32_t select_by_mask(unsigned long long mask, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ double select_by_mask(unsigned long long mask, double a, double b)
+{
+    const uint64_t ab = __builtin_bit_cast(uint64_t, a), bb = __builtin_bit_cast(uint64_t, b);
+    const uint32_t lo = select_by_mask(mask, (uint32_t)ab, (uint32_t)bb);
+    const uint32_t hi = select_by_mask(mask, (uint32_t)(ab >> 32), (uint32_t)(bb >> 32));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;     // a 32-bit LDS address
+
 template <int C, int T>
 struct PackedChain {
     WavePriority prio;
     const char *Kb;
     uint32_t col_bytes, tab_bytes;
     uint32_t *wi;               // LDS: this lane's chain's positions
+    uint32_t *dummy;            // LDS: a word of this lane's chain nobody reads (target of the commits not taken)
     int lane, g, q;             // chain of the wave this lane works for, lane within the chain
     int n_omega, gmax;
     uint32_t lane_off;          // byte offset of this lane's first tau slot in a column (clamped into the column)
@@ -213,6 +232,7 @@ __device__ __forceinline__ void packed_move_loop(PackedChain<C, T> &c, const int
         decode_packed<NCOL, C, T>(c, MOVE, (uint32_t)(base + (c.q < cnt ? c.q : cnt - 1)), window, d);
         unsigned long long inb_bits = __builtin_amdgcn_ballot_w64(d.inb != 0);
         unsigned long long stale = 0ull;         // proposals re-decoded while their columns were in flight
+        unsigned long long eval_all = 0ull, acc_all = 0ull;   // this group's evaluated / accepted proposals (one bit each)
 
         TauVec<T> kn[DEPTH][NCOL], ko[DEPTH][NCOL];
         // column indices of the next step to request, fetched from the decoding lanes one step ahead of the loads
@@ -304,24 +324,26 @@ __device__ __forceinline__ void packed_move_loop(PackedChain<C, T> &c, const int
             const bool ok = metropolis(c.chi2, sum, c.inv2theta, d.lnu);
             const unsigned long long accbits = __builtin_amdgcn_ballot_w64(ok) & evalbits;
             record(accbits, sum);
+            eval_all |= evalbits;
+            acc_all |= accbits;
+            // free:310-318 for the accepting chains, without a branch: every lane keeps or replaces its chain's state
+            const unsigned long long lanes = expand_chain_bits<C>(accbits >> j);
 #pragma unroll
-            for (int g = 0; g < C; ++g) evaluated[g] += (uint32_t)((evalbits >> (g * LPC + j)) & 1ull);
-            if (accbits != 0ull) {                                    // free:310-318 for the accepting chains
-                const unsigned long long lanes = expand_chain_bits<C>(accbits >> j);
-                const bool mine = ((lanes >> c.lane) & 1ull) != 0ull;
+            for (int t = 0; t < T; ++t) c.gbar[t] = select_by_mask(lanes, gnew[t], c.gbar[t]);
+            c.chi2 = select_by_mask(lanes, sum, c.chi2);
+            c.chi2_min = __builtin_fmin(c.chi2, c.chi2_min);
+            // the accepting proposals' own lanes store the new positions, every other lane writes its chain's spare word
 #pragma unroll
-                for (int t = 0; t < T; ++t) c.gbar[t] = mine ? gnew[t] : c.gbar[t];
-                c.chi2 = mine ? sum : c.chi2;
-                c.chi2_min = (c.chi2 < c.chi2_min) ? c.chi2 : c.chi2_min;
-                if ((accbits >> c.lane) & 1ull) {                     // the proposal's own lane commits the positions
-#pragma unroll
-                    for (int q = 0; q < NCOL; ++q) c.wi[d.k[q]] = (uint32_t)d.wnew[q];
-                }
+            for (int q = 0; q < NCOL; ++q) {
+                const uint32_t a_pos = (uint32_t)(uintptr_t)(lds_u32 *)&c.wi[d.k[q]];
+                const uint32_t a_spare = (uint32_t)(uintptr_t)(lds_u32 *)c.dummy;
+                lds_u32 *dst = (lds_u32 *)(uintptr_t)select_by_mask(accbits, a_pos, a_spare);
+                *dst = (uint32_t)d.wnew[q];
+            }
+            if (accbits != 0ull) {
                 // other lanes of the chain re-read these positions below: without the fence the compiler forwards a
                 // lane's own last value of wi[k] instead of loading what the committing lane stored
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                for (int g = 0; g < C; ++g) accepted[g] += (int)((accbits >> (g * LPC + j)) & 1ull);
                 // later proposals of an accepting chain that use a moved delta: decode again
                 int mk[NCOL];
 #pragma unroll
@@ -372,6 +394,11 @@ __device__ __forceinline__ void packed_move_loop(PackedChain<C, T> &c, const int
                   issue(std::integral_constant<int, Us>{}), start(j0 + Us + DEPTH + 1)), ...);
             }(std::make_integer_sequence<int, DEPTH>{});
         }
+#pragma unroll
+        for (int g = 0; g < C; ++g) {
+            evaluated[g] += (uint32_t)__builtin_popcountll(eval_all & (CHAIN_LANES << (g * LPC)));
+            accepted[g] += __builtin_popcountll(acc_all & (CHAIN_LANES << (g * LPC)));
+        }
     }
 #pragma unroll
     for (int g = 0; g < C; ++g) {
@@ -414,6 +441,7 @@ free_stage_packed_kernel(const FreeParams p)
     c.g = lane / LPC;
     c.q = lane % LPC;
     c.wi = s_wi + (size_t)c.g * (size_t)p.wi_stride;
+    c.dummy = reinterpret_cast<uint32_t *>(s_sc + 12 * c.g + 11);
     c.prio.init(p.prio_shift);
     c.n_omega = p.n_omega;
     c.gmax = p.gmax;
