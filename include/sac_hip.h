@@ -232,6 +232,22 @@ typedef struct {
 int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sac_proposal_t *props, int64_t n,
                double *chi2_new, int32_t *accepted);
 
+/* The same for SAC_KIND_PEAK (peak:382-996).  transfer = 0: a frequency move of n = 1..3 deltas, amplitudes stay
+ * (Gbar + A (K_new - K_old) per delta, peak:415-423, 486-494, 573-585, 666-673); transfer = 1: a weight transfer, n = 2 or
+ * 4, pairs (k[0], k[1]) [and (k[2], k[3])] = (+ axis delta, - axis delta) with their new amplitudes (peak:758-764, 957-967).
+ * k = 0-based index into the chain's state array (peak+, cont+, peak-, cont-): it selects the axis and the table Kp / Kn.
+ * Starts from the handle's stored Gbar / chi2 (sac_init_gbar rebuilds them from scratch as a sweep does, peak:1072). */
+typedef struct {
+    int32_t n;
+    int32_t transfer;
+    int32_t k[4];
+    int64_t w_new[4];
+    double  A_new[4];    /* transfer = 1 only */
+    double  u;           /* the accept draw rand() (accept when u <= P, peak:428) */
+} sac_peak_proposal_t;
+int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, const sac_peak_proposal_t *props, int64_t n,
+                    double *chi2_new, int32_t *accepted);
+
 /* Debug/parity: record every proposal of one chain (up to capacity) during the following stages. */
 int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);
 int sac_get_move_log(sac_handle_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
@@ -307,6 +323,21 @@ int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side, double *o
 /* omega_avg, A_avg (edge:83-84, 1314-1315): [N_w+1, 2] accumulated sums */
 int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, double *A_avg);
 int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min);
+/* Parity / debug entry (no counterpart in the reference): an explicit stream of position proposals on one
+ * chain -- new frequencies w_new[w_offset .. w_offset+n-1] for the n consecutive deltas k .. k+n-1 (Julia's 1-based index,
+ * 2 .. N_w+1) of one side, and the accept draw.  n = 1: what single_edge_move / single_cont_move evaluate once index, shift
+ * and order check are done (edge:856-880, 1176-1186); n > 1: multi_edge_move (edge:938-964).  Accepted when u < P (edge:864)
+ * and committed (omega, K_curr, Gbar, chi2).  The ordering constraints (check_order) are the caller's business. */
+typedef struct {
+    int32_t side;       /* column of the state arrays */
+    int32_t k;          /* first moved delta */
+    int32_t n;          /* deltas moved, <= 64 */
+    int32_t reserved;
+    int64_t w_offset;   /* first new frequency in w_new[] */
+    double  u;          /* the accept draw rand() */
+} sac_edge_proposal_t;
+int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const sac_edge_proposal_t *props, int64_t n,
+                    const double *w_new, int64_t n_w, double *chi2_new, int32_t *accepted);
 int sac_edge_set_move_log(sac_edge_t *h, int32_t chain, int64_t capacity);
 int sac_edge_get_move_log(sac_edge_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
 

@@ -986,6 +986,151 @@ extern "C" int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, dou
     return SAC_OK;
 }
 
+// Explicit proposal stream for one chain (parity / debug entry): new positions of n consecutive deltas
+// k .. k+n-1 of one side (n = 1: single_edge_move / single_cont_move, edge:856-880, 1176-1186; n > 1: multi_edge_move,
+// edge:938-964) and the accept draw.  Evaluation is the sweep kernel's: Taylor lookup per delta (edge:626-633), Gbar_new
+// accumulated in index order, chi2 by the canonical tree, accept when u < P (edge:864), commit of omega, K_curr, Gbar, chi2.
+struct EdgeReplayProp { int side, k, n, reserved; long long w_offset; double u; };
+
+template <int NTL>
+__global__ void __launch_bounds__(64) edge_replay_kernel(const EdgeParams p, int chain, const EdgeReplayProp *props, long long n_props,
+                                                         const double *w_new, double *chi2_out, int *acc_out)
+{
+    const int lane = lane_id();
+    const size_t cb = (size_t)p.ntp * 8u;
+    uint32_t off[NTL];
+    double gbar[NTL], G[NTL], sinv[NTL];
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        gbar[t] = gbar_g[j];
+        G[t] = p.G[j];
+        sinv[t] = p.sinv[j];
+    }
+    EdgeScalars *sc = p.sc + chain;
+    double chi2 = sc->chi2, chi2_min = sc->chi2_min;
+    unsigned long long lookups = 0;
+    for (long long i = 0; i < n_props; ++i) {
+        const EdgeReplayProp pr = props[i];
+        const size_t base = ((size_t)chain * 2u + (size_t)pr.side) * (size_t)p.S;
+        double *w = p.w + base;
+        const double *A = p.A + base;
+        char *kc = reinterpret_cast<char *>(p.kcurr) + base * cb;
+        char *kw = reinterpret_cast<char *>(p.knew) + base * cb;
+        const char *tab = reinterpret_cast<const char *>(p.tab[pr.side]);
+        double gn[NTL];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
+        for (int j = 0; j < pr.n; ++j) {
+            const double wk = w_new[pr.w_offset + j];
+            // floor(w / dw) by the correctly rounded division (edge:626)
+            const int wi = (int)__builtin_floor(wk / p.dwg);
+            const double d = wk - ((double)wi * p.dwg);
+            const double d2 = d * d;
+            long long col = (long long)wi - p.wi0;
+            col = col < 0 ? 0 : (col >= p.n_grid ? p.n_grid - 1 : col);
+            const char *b = tab + (size_t)col * 3u * cb;
+            const double Ak = A[pr.k + j];
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                const double k0 = *reinterpret_cast<const double *>(b + off[t]);
+                const double k1 = *reinterpret_cast<const double *>(b + cb + off[t]);
+                const double k2 = *reinterpret_cast<const double *>(b + 2 * cb + off[t]);
+                const double kn = (k0 + (k1 * d)) + (k2 * d2);
+                const double old = *reinterpret_cast<const double *>(kc + (size_t)(pr.k + j) * cb + off[t]);
+                gn[t] = gn[t] + Ak * (kn - old);
+                *reinterpret_cast<double *>(kw + (size_t)(pr.k + j) * cb + off[t]) = kn;
+            }
+        }
+        lookups += (unsigned long long)pr.n;
+        double term = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const double e = (gn[t] - G[t]) * sinv[t];
+            term = (t == 0) ? e * e : term + e * e;
+        }
+        const double chi2_new = wave_sum_uniform(term);
+        const bool acc = log_u01(pr.u) < (chi2 - chi2_new) * p.inv2theta;      // rand() < P
+        if (acc) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+            for (int j = 0; j < pr.n; ++j) {
+#pragma unroll
+                for (int t = 0; t < NTL; ++t)
+                    *reinterpret_cast<double *>(kc + (size_t)(pr.k + j) * cb + off[t]) =
+                        *reinterpret_cast<const double *>(kw + (size_t)(pr.k + j) * cb + off[t]);
+            }
+            if (lane < pr.n) w[pr.k + lane] = w_new[pr.w_offset + lane];
+            chi2 = chi2_new;
+            if (chi2_new < chi2_min) chi2_min = chi2_new;
+        }
+        __syncthreads();
+        if (lane == 0) { chi2_out[i] = chi2_new; acc_out[i] = acc ? 1 : 0; }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        if (j < p.n_tau) gbar_g[j] = gbar[t];
+    }
+    if (lane == 0) { sc->chi2 = chi2; sc->chi2_min = chi2_min; sc->counters[4] += lookups; }
+}
+
+extern "C" int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const sac_edge_proposal_t *props, int64_t n,
+                               const double *w_new, int64_t n_w, double *chi2_new, int32_t *accepted)
+{
+    if (!h || (n > 0 && (!props || !w_new))) return efail(SAC_E_INVALID, "sac_edge_replay: null argument");
+    if (chain < 0 || chain >= h->cfg.n_chains) return efail(SAC_E_INVALID, "sac_edge_replay: chain %d outside 0..%d", chain, h->cfg.n_chains - 1);
+    if (!h->problem || !h->state_set || !h->gbar_set)
+        return efail(SAC_E_STATE, "sac_edge_replay: needs the problem, the state and sac_edge_init_gbar first");
+    if (!(theta > 0.0) || !std::isfinite(theta)) return efail(SAC_E_INVALID, "sac_edge_replay: theta=%g", theta);
+    static_assert(sizeof(EdgeReplayProp) == sizeof(sac_edge_proposal_t), "proposal layout");
+    const double w_lo = (double)h->cfg.wi_0 * h->cfg.d_omega, w_hi = (double)(h->cfg.wi_0 + h->cfg.n_grid - 1) * h->cfg.d_omega;
+    for (int64_t i = 0; i < n; ++i) {
+        const sac_edge_proposal_t &q = props[i];
+        if (q.side < 0 || q.side >= h->cfg.n_rl) return efail(SAC_E_INVALID, "sac_edge_replay: proposal %lld: side %d", (long long)i, q.side);
+        if (q.n < 1 || q.n > 64 || q.k < 2 || q.k + q.n - 1 > h->cfg.n_omega + 1)
+            return efail(SAC_E_INVALID, "sac_edge_replay: proposal %lld: deltas %d..%d outside 2..%d (at most 64 at a time)", (long long)i,
+                         q.k, q.k + q.n - 1, h->cfg.n_omega + 1);
+        if (q.w_offset < 0 || q.w_offset + q.n > n_w)
+            return efail(SAC_E_INVALID, "sac_edge_replay: proposal %lld: positions %lld.. outside w_new[%lld]", (long long)i,
+                         (long long)q.w_offset, (long long)n_w);
+        for (int j = 0; j < q.n; ++j) {
+            const double x = w_new[q.w_offset + j];
+            if (!(x >= w_lo && x <= w_hi))
+                return efail(SAC_E_INVALID, "sac_edge_replay: proposal %lld: frequency %g outside the kernel grid [%g, %g]", (long long)i, x, w_lo, w_hi);
+        }
+    }
+    if (n == 0) return SAC_OK;
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    EdgeReplayProp *dP = nullptr;
+    double *dW = nullptr, *dC = nullptr;
+    int *dAcc = nullptr;
+    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * sizeof(EdgeReplayProp)));
+    HIP_TRY(hipMalloc((void **)&dW, (size_t)n_w * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dC, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dAcc, (size_t)n * sizeof(int)));
+    HIP_TRY(hipMemcpy(dP, props, (size_t)n * sizeof(EdgeReplayProp), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dW, w_new, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice));
+    EdgeParams p;
+    fill_params(h, p);
+    p.inv2theta = 1.0 / (2.0 * theta);
+    if (h->cfg.n_tau <= 64) hipLaunchKernelGGL(edge_replay_kernel<1>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dW, dC, dAcc);
+    else hipLaunchKernelGGL(edge_replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dW, dC, dAcc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dP));
+    HIP_TRY(hipFree(dW));
+    HIP_TRY(hipFree(dC));
+    HIP_TRY(hipFree(dAcc));
+    return SAC_OK;
+}
+
 extern "C" int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min)
 {
     if (!h) return efail(SAC_E_INVALID, "sac_edge_get_gbar: null handle");

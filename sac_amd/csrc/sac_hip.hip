@@ -548,6 +548,92 @@ __global__ void __launch_bounds__(64) replay_kernel(const FreeParams p, int chai
     if (lane == 0) { p.sc[chain].chi2 = chi2; p.sc[chain].chi2_min = chi2_min; }
 }
 
+// The same for the peak parameterisation: a proposal touches up to four deltas of the chain's state array (peak+, cont+,
+// peak-, cont-; the index selects the axis and with it the table Kp / Kn).  transfer = 0: frequency moves, amplitudes
+// stay (peak:415-423, 486-494, 573-585, 666-673: Gbar + A (K_new - K_old) per delta); transfer = 1: weight transfer
+// between the axes, pairs (k[0], k[1]) [and (k[2], k[3])] = (+ axis, - axis) with new amplitudes (peak:758-764, 957-967:
+// (((Gbar + A'_p K'_p) + A'_n K'_n) - A_p K_p) - A_n K_n per pair).
+struct PeakReplayProp { int n; int transfer; int k[4]; long long w_new[4]; double A_new[4]; double u; };
+
+template <int NTL>
+__global__ void __launch_bounds__(64) peak_replay_kernel(const PeakParams pp, int chain, const PeakReplayProp *props, long long n,
+                                                         double *chi2_out, int *acc_out)
+{
+    const FreeParams &p = pp.f;
+    const int lane = lane_id();
+    uint32_t *wi = p.wi + (size_t)chain * (size_t)p.wi_stride;
+    double *A = p.A + (size_t)chain * (size_t)p.wi_stride;
+    double *gbar_g = p.gbar + (size_t)chain * SAC_MAX_N_TAU;
+    const char *Kb[2] = {reinterpret_cast<const char *>(p.K), reinterpret_cast<const char *>(pp.Kn)};
+    const size_t col_bytes = (size_t)p.ntp * 8u;
+    const int n_axis = pp.n_p + pp.n_cont;
+    uint32_t off[NTL];
+    double gbar[NTL], G[NTL], sinv[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        off[t] = (uint32_t)((j < p.ntp) ? j : p.ntp - 1) * 8u;
+        gbar[t] = gbar_g[j];
+        G[t] = p.G[j];
+        sinv[t] = p.sinv[j];
+    }
+    double chi2 = pp.psc[chain].chi2, chi2_min = pp.psc[chain].chi2_min;
+    for (long long i = 0; i < n; ++i) {
+        const PeakReplayProp pr = props[i];
+        double gn[NTL], fn[4][NTL], fo[4][NTL], a_old[4];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) gn[t] = gbar[t];
+        for (int e = 0; e < pr.n; ++e) {
+            const char *tab = Kb[pr.k[e] >= n_axis ? 1 : 0];
+            a_old[e] = A[pr.k[e]];
+            const size_t cn = (size_t)pr.w_new[e] * col_bytes, co = (size_t)wi[pr.k[e]] * col_bytes;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+                fn[e][t] = *reinterpret_cast<const double *>(tab + cn + off[t]);
+                fo[e][t] = *reinterpret_cast<const double *>(tab + co + off[t]);
+            }
+        }
+        if (!pr.transfer) {
+            for (int e = 0; e < pr.n; ++e)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) gn[t] = gn[t] + a_old[e] * (fn[e][t] - fo[e][t]);
+        } else {
+            for (int q = 0; q < pr.n; q += 2)
+#pragma unroll
+                for (int t = 0; t < NTL; ++t)
+                    gn[t] = (((gn[t] + (pr.A_new[q] * fn[q][t])) + (pr.A_new[q + 1] * fn[q + 1][t])) - (a_old[q] * fo[q][t]))
+                            - (a_old[q + 1] * fo[q + 1][t]);
+        }
+        double term = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+            const double d = (gn[t] - G[t]) * sinv[t];
+            term = (t == 0) ? d * d : term + d * d;
+        }
+        const double chi2_new = wave_sum_uniform(term);
+        const bool acc = metropolis(chi2, chi2_new, p.inv2theta, log_u01(pr.u));
+        if (acc) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) gbar[t] = gn[t];
+            if (lane == 0)
+                for (int e = 0; e < pr.n; ++e) {
+                    wi[pr.k[e]] = (uint32_t)pr.w_new[e];
+                    if (pr.transfer) A[pr.k[e]] = pr.A_new[e];
+                }
+            chi2 = chi2_new;
+            if (chi2_new < chi2_min) chi2_min = chi2_new;
+            __syncthreads();
+        }
+        if (lane == 0) { chi2_out[i] = chi2_new; acc_out[i] = acc ? 1 : 0; }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+        const int j = lane + 64 * t;
+        if (j < p.n_tau) gbar_g[j] = gbar[t];
+    }
+    if (lane == 0) { pp.psc[chain].chi2 = chi2; pp.psc[chain].chi2_min = chi2_min; }
+}
+
 // chi^2 of a given Gbar (sac_set_gbar consistency helper is host side; this kernel sums replicas)
 __global__ void hist_sum_kernel(const double *hist, long long n_grid, int copies, double *dst)
 {
@@ -1704,6 +1790,58 @@ extern "C" int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sa
     p.inv2theta = 1.0 / (2.0 * theta);
     if (h->cfg.n_tau <= 64) hipLaunchKernelGGL(replay_kernel<1>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dC, dAcc);
     else hipLaunchKernelGGL(replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dC, dAcc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dP));
+    HIP_TRY(hipFree(dC));
+    HIP_TRY(hipFree(dAcc));
+    return stage_end(h, 0, 0);
+}
+
+extern "C" int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, const sac_peak_proposal_t *props, int64_t n,
+                               double *chi2_new, int32_t *accepted)
+{
+    if (!h || (n > 0 && !props)) return fail(SAC_E_INVALID, "sac_replay_peak: null argument");
+    if (!h->peak) return fail(SAC_E_INVALID, "sac_replay_peak: not a SAC_KIND_PEAK handle");
+    if (chain < 0 || chain >= h->cfg.n_chains) return fail(SAC_E_INVALID, "sac_replay_peak: chain %d outside 0..%d", chain, h->cfg.n_chains - 1);
+    int rc;
+    if ((rc = stage_begin(h, "sac_replay_peak", n, theta))) return rc;
+    static_assert(sizeof(PeakReplayProp) == sizeof(sac_peak_proposal_t), "proposal layout");
+    const int n_axis = h->cfg.n_omega + h->cfg.n_peak;
+    const int n_used = h->sample_neg ? 2 * n_axis : n_axis;
+    for (int64_t i = 0; i < n; ++i) {
+        const sac_peak_proposal_t &q = props[i];
+        if (q.n < 1 || q.n > 4 || (q.transfer && q.n != 2 && q.n != 4) || (!q.transfer && q.n > 3))
+            return fail(SAC_E_INVALID, "sac_replay_peak: proposal %lld: %d deltas, transfer=%d", (long long)i, q.n, q.transfer);
+        for (int e = 0; e < q.n; ++e) {
+            if (q.k[e] < 0 || q.k[e] >= n_used)
+                return fail(SAC_E_INVALID, "sac_replay_peak: proposal %lld: delta index %d outside 0..%d", (long long)i, q.k[e], n_used - 1);
+            if (q.w_new[e] < 0 || q.w_new[e] > h->cfg.wi_m)
+                return fail(SAC_E_INVALID, "sac_replay_peak: proposal %lld: position %lld outside [0, %lld]", (long long)i,
+                            (long long)q.w_new[e], (long long)h->cfg.wi_m);
+            if (q.transfer && !(std::isfinite(q.A_new[e]) && q.A_new[e] >= 0))    // the reference rejects A' < 0 before evaluating (peak:952)
+                return fail(SAC_E_INVALID, "sac_replay_peak: proposal %lld: amplitude %g", (long long)i, q.A_new[e]);
+            if (q.transfer && ((q.k[e] >= n_axis) != ((e & 1) == 1)))
+                return fail(SAC_E_INVALID, "sac_replay_peak: proposal %lld: a transfer pairs a + axis delta with a - axis delta", (long long)i);
+            for (int f = 0; f < e; ++f)
+                if (q.k[e] == q.k[f]) return fail(SAC_E_INVALID, "sac_replay_peak: proposal %lld repeats delta %d", (long long)i, q.k[e]);
+        }
+    }
+    if (n == 0) return stage_end(h, 0, 0);
+    PeakReplayProp *dP = nullptr;
+    double *dC = nullptr;
+    int *dAcc = nullptr;
+    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * sizeof(PeakReplayProp)));
+    HIP_TRY(hipMalloc((void **)&dC, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&dAcc, (size_t)n * sizeof(int)));
+    HIP_TRY(hipMemcpy(dP, props, (size_t)n * sizeof(PeakReplayProp), hipMemcpyHostToDevice));
+    PeakParams pp;
+    fill_peak_params(h, pp);
+    pp.f.inv2theta = 1.0 / (2.0 * theta);
+    if (h->cfg.n_tau <= 64) hipLaunchKernelGGL(peak_replay_kernel<1>, dim3(1), dim3(64), 0, h->stream, pp, (int)chain, dP, (long long)n, dC, dAcc);
+    else hipLaunchKernelGGL(peak_replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, pp, (int)chain, dP, (long long)n, dC, dAcc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));

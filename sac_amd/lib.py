@@ -21,7 +21,7 @@ EXPORTS = [
     "sac_edge_get_move_log",
     "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
-    "sac_set_chains_per_wave", "sac_get_chains_per_wave",
+    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_replay_peak", "sac_edge_replay",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -98,6 +98,11 @@ def _table_spec(kernel_type, i_first, d_omega, beta, offset=0.0, mirror=0, negat
 
 PROPOSAL = np.dtype([("move", "<i4"), ("k", "<i4", 3), ("w_new", "<i8", 3), ("u", "<f8")])
 
+PEAK_PROPOSAL = np.dtype([("n", "<i4"), ("transfer", "<i4"), ("k", "<i4", 4), ("w_new", "<i8", 4), ("A_new", "<f8", 4),
+                          ("u", "<f8")])
+
+EDGE_PROPOSAL = np.dtype([("side", "<i4"), ("k", "<i4"), ("n", "<i4"), ("reserved", "<i4"), ("w_offset", "<i8"), ("u", "<f8")])
+
 MOVE_REC = np.dtype([("chi2_new", "<f8"), ("flags", "<i4"), ("move", "<i4")])
 
 
@@ -138,6 +143,7 @@ def load_library():
     L.sac_copy_chain.argtypes = [vp, C.c_int32, C.c_int32]
     L.sac_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_get_chain_chi2.argtypes = [vp, dp, dp]
+    L.sac_replay_peak.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_build_table.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_build_table_noalloc.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_get_table.argtypes = [vp, C.c_int32, dp]
@@ -161,6 +167,7 @@ def load_library():
     L.sac_edge_get_avg.argtypes = [vp, C.c_int32, dp, dp]
     L.sac_edge_get_gbar.argtypes = [vp, C.c_int32, dp, dp, dp]
     L.sac_edge_set_move_log.argtypes = [vp, C.c_int32, C.c_int64]
+    L.sac_edge_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, C.c_int64, dp, vp]
     L.sac_edge_get_move_log.argtypes = [vp, vp, C.c_int64, ip]
     for name in EXPORTS:
         if name != "sac_last_error":
@@ -340,6 +347,14 @@ class SacHandle:
         self._check(self.L.sac_replay(self.h, chain, float(theta), props.ctypes.data, n, _dp(c2), acc.ctypes.data))
         return c2, acc
 
+    def replay_peak(self, props, theta, chain=0):
+        """props: array of PEAK_PROPOSAL records.  Returns (chi2_new[n], accepted[n])."""
+        props = np.ascontiguousarray(props, dtype=PEAK_PROPOSAL)
+        n = len(props)
+        c2, acc = np.empty(n), np.empty(n, dtype=np.int32)
+        self._check(self.L.sac_replay_peak(self.h, chain, float(theta), props.ctypes.data, n, _dp(c2), acc.ctypes.data))
+        return c2, acc
+
     def chain_chi2(self):
         a, b = np.empty(self.cfg.n_chains), np.empty(self.cfg.n_chains)
         self._check(self.L.sac_get_chain_chi2(self.h, _dp(a), _dp(b)))
@@ -499,6 +514,16 @@ class SacEdgeHandle:
         c, m = C.c_double(), C.c_double()
         self._check(self.L.sac_edge_get_gbar(self.h, chain, _dp(g), C.byref(c), C.byref(m)))
         return g, c.value, m.value
+
+    def replay(self, props, w_new, theta, chain=0):
+        """props: array of EDGE_PROPOSAL records, w_new: the new frequencies they index.  Returns (chi2_new[n], accepted[n])."""
+        props = np.ascontiguousarray(props, dtype=EDGE_PROPOSAL)
+        w_new = np.ascontiguousarray(w_new, dtype=np.float64)
+        n = len(props)
+        c2, acc = np.empty(n), np.empty(n, dtype=np.int32)
+        self._check(self.L.sac_edge_replay(self.h, chain, float(theta), props.ctypes.data, n, _dp(w_new), len(w_new), _dp(c2),
+                                           acc.ctypes.data))
+        return c2, acc
 
     def set_move_log(self, chain, capacity):
         self._check(self.L.sac_edge_set_move_log(self.h, chain, capacity))

@@ -16,23 +16,41 @@ CV = os.path.join(os.path.dirname(__file__), "golden", "cv")
 
 
 def test_anneal_curve_follows_reference_run(tmp_path):
-    s = FreeSAC.from_infile(f"{CV}/run001a_free_in_free.in", n_chains=64, seed=2025)
+    """The reference's own schedule (in_free.in: 500 + 500 sweeps per Theta) on 64 chains, first 60 ladder points.
+    Per Theta the reference's anneal.csv holds ONE chain's 500-sweep average; a GPU chain's 500-sweep average is a draw
+    from the same distribution if the samplers agree, so with m, s the mean and scatter over the 64 GPU chains
+        z = (m - ref) / (s * sqrt(1 + 1/64))
+    is standard normal.  Required: |z| < 4 at every Theta, <z^2> < 2, |<z>| < 0.6 (measured: max 2.6, 1.2, 0.35)."""
+    n_chains, n_pts = 64, 60
+    s = FreeSAC.from_infile(f"{CV}/run001a_free_in_free.in", n_chains=n_chains, seed=2025)
     s.G_file = f"{CV}/t_001a.in"
     s.output_folder = str(tmp_path / "out")
-    s.N_anneal, s.anneal_steps, s.sample_steps = 70, 100, 200     # reference: 150 x 500, 5000
+    assert (s.anneal_steps, s.N_anneal) == (500, 150)
+    s.N_anneal, s.sample_steps = n_pts, 500                        # reference: 150 points, 5000 final sweeps
     s.chi2_anneal = np.zeros(s.N_anneal)
     s.tol = 1e-6                                                   # cross_val.jl:50
-    theta_opt = s.run()
     ref = np.loadtxt(f"{CV}/run001a_free_anneal.csv", delimiter=",", skiprows=1)
+    per_chain = []
+    s.init_outfiles()
+    s.initialize()
+    s.h.set_state(windows=np.full(4, s.prob.window))
+    s.fast_anneal()
+    s.main_anneal(False, on_stage=lambda i, th: per_chain.append(
+        np.array([s.h.chain_stats(c)["sampled_chi2"] for c in range(n_chains)]) / s.td.n_tau))
+    theta_opt = s.optimal_theta()
+    s.anneal_steps = 50                                            # the ramp of the final stage costs 110 x this
+    s.final_anneal(theta_opt)
     got = np.loadtxt(s.anneal_file, delimiter=",", skiprows=1)
     n = len(got)
-    assert n == 70
+    assert n == n_pts == len(per_chain)
     assert np.array_equal(got[:, 1], ref[:n, 1])                   # same Theta ladder, same rounding
-    # <chi^2>/N_tau: a single reference chain with 500 sweeps per point scatters by a few percent;
-    # the GPU value is a 64-chain mean
-    ratio = got[:, 3] / ref[:n, 3]
-    assert np.abs(np.log(ratio)).max() < 0.12, ratio
-    assert abs(np.log(ratio).mean()) < 0.03
+    v = np.array(per_chain)
+    m, sd = v.mean(axis=1), v.std(axis=1, ddof=1)
+    np.testing.assert_allclose(m, got[:, 3], atol=1e-4)            # what anneal.csv prints is the chain mean
+    z = (m - ref[:n, 3]) / (sd * np.sqrt(1 + 1 / n_chains))
+    print("z", np.round(z, 2))
+    assert np.abs(z).max() < 4.0, z
+    assert (z ** 2).mean() < 2.0 and abs(z.mean()) < 0.6, ((z ** 2).mean(), z.mean())
     # chi2_min of 64 chains is a minimum over more samples: never far above the single chain's
     assert (got[10:, 2] < ref[10:n, 2] * 1.05).all()
     # outputs exist in the reference's layout
@@ -40,8 +58,6 @@ def test_anneal_curve_follows_reference_run(tmp_path):
     assert sw[0] == "omega,S" and len(sw) > 20
     smp = open(s.sample_file).read().split("\n")
     assert smp[0] == "i,a,theta,chi2_min,chi2_avg" and len(smp) >= 2
-    log = open(os.path.join(s.output_folder, "log.txt")).read()
-    assert "Beginning Main Anneal." in log and "Final Anneal Finished." in log
     assert 0 < theta_opt <= 10.0
 
 

@@ -56,3 +56,69 @@ def test_edge_anneal_follows_reference_run(tmp_path):
     sw = np.genfromtxt(os.path.join(s.output_folder, "sw000_1.dat"), delimiter=",", skip_header=1)
     # normalised spectrum: integral = norm * pi, first weight at the edge
     assert sw[np.argmax(sw[:, 1] > 0), 0] == pytest.approx(1.57, abs=0.03)
+    # against the spectra the reference run wrote (edge:1514-1637): sw = histogram on the d_omega_h grid, dw = the
+    # self-generated grid of the averaged delta positions (N_e + 1 rows).  Same layout, same integral, the edge in the same
+    # place, the same distribution of the weight above it (this run cools 10 x faster than the reference: loose bounds).
+    rsw = np.genfromtxt(f"{REF}/sw000_1.dat", delimiter=",", skip_header=1)
+    dw = np.genfromtxt(os.path.join(s.output_folder, "dw000_1.dat"), delimiter=",", skip_header=1)
+    rdw = np.genfromtxt(f"{REF}/dw000_1.dat", delimiter=",", skip_header=1)
+    assert open(os.path.join(s.output_folder, "sw000_1.dat")).readline() == open(f"{REF}/sw000_1.dat").readline()
+    assert dw.shape == rdw.shape == (81, 4)
+    assert np.allclose(np.diff(sw[:, 0]), 0.005, atol=1e-9)
+    print("integral", sw[:, 1].sum() * 0.005, rsw[:, 1].sum() * 0.005, "first dw row", dw[0], rdw[0], "last", dw[-1], rdw[-1])
+    assert sw[:, 1].sum() == pytest.approx(rsw[:, 1].sum(), rel=0.02)
+    assert abs(dw[0, 0] - rdw[0, 0]) < 0.015 and dw[0, 1] == 0 and rdw[0, 1] == 0     # the edge itself carries no weight
+    assert abs(dw[-1, 0] / rdw[-1, 0] - 1) < 0.15                                      # where the last delta sits
+    grid = np.linspace(1.5, 4.5, 301)
+    ca = np.interp(grid, sw[:, 0], np.cumsum(sw[:, 1]) / sw[:, 1].sum())
+    cb = np.interp(grid, rsw[:, 0], np.cumsum(rsw[:, 1]) / rsw[:, 1].sum())
+    print("CDF difference", np.abs(ca - cb).max())
+    assert np.abs(ca - cb).max() < 0.08
+    # the integral of the dw form (trapezoid on its own grid) equals the histogram's
+    tr = ((dw[1:, 1] + dw[:-1, 1]) / 2 * np.diff(dw[:, 0])).sum()
+    rtr = ((rdw[1:, 1] + rdw[:-1, 1]) / 2 * np.diff(rdw[:, 0])).sum()
+    print("dw integral", tr, rtr)
+    assert tr == pytest.approx(rtr, rel=0.1)
+
+
+def test_edge_reference_schedule_z_test(tmp_path):
+    """The first 8 points of the reference's own Theta ladder with the reference's own sweeps per stage (equilibration
+    5 x 600 x 20, then 20 bins of 600 (1 - i / 48) sweeps per Theta; only the kernel grid is 10 x coarser) on 32 chains.  The
+    reference prints the error bars of its own run (sigma of the bin means: chi2_sigma, edge_R_sigma, n0_R_sigma), so with
+    m, s the mean and scatter of the chains' stage averages
+        z = (m - ref) / sqrt(s^2 / 32 + sigma_ref^2)
+    is of order one if both sample the same distribution.  Required: |z| < 4.5 for <chi^2>, the edge location and n0 / N_e at
+    every Theta (measured maxima 2.4, 3.4, 1.9; the reference's bins are correlated for the slow edge mode, which makes its
+    sigma an underestimate and the edge z-scores the largest) and a mean z within +-1.5."""
+    n_chains, n_pts = 32, 8
+    s = EdgeSAC.from_infile(f"{REF}/in_edge.in", n_chains=n_chains, seed=3)
+    s.G_file = f"{REF}/t.in"
+    s.output_folder = str(tmp_path / "out")
+    s.d_omega = 1e-4
+    assert (s.anneal_steps, s.bins, s.N_anneal, s.f_anneal) == (600, 20, 200, 1.05)
+    os.makedirs(s.output_folder, exist_ok=True)
+    s.write_log("start", "w")
+    s.init_outfiles()
+    s.initialize()
+    ref = np.genfromtxt(f"{REF}/anneal.csv", delimiter=",", skip_header=1)
+    nt = s.td.n_tau
+    s.run_bins(5 * s.anneal_steps, s.bins, s.theta_0)                         # edge:2052
+    theta, i_trans = s.theta_0, s.N_anneal * 0.2
+    zs = {"chi2": [], "edge": [], "n0": []}
+    for i in range(1, n_pts + 1):                                             # edge:1651-1660
+        steps = int(np.ceil(s.anneal_steps * (1 - (5 / 6) * i / i_trans)))
+        s.run_bins(steps, s.bins, theta)
+        per = [s.h.results(c) for c in range(n_chains)]
+        rr = ref[i]
+        assert rr[1] == pytest.approx(theta, rel=1e-6)
+        for name, col, scol, vals in (("chi2", 3, 4, [p["chi2_res"][1] / nt for p in per]),
+                                      ("edge", 5, 9, [p["edge_res"][1, 0] for p in per]),
+                                      ("n0", 7, 11, [p["n0_res"][1, 0] for p in per])):
+            v = np.array(vals)
+            zs[name].append((v.mean() - rr[col]) / np.sqrt(v.var(ddof=1) / n_chains + rr[scol] ** 2))
+        theta /= s.f_anneal
+    for name, z in zs.items():
+        z = np.array(z)
+        print(name, "z", np.round(z, 2))
+        assert np.abs(z).max() < 4.5, (name, z)
+        assert abs(z.mean()) < 1.5, (name, z.mean())

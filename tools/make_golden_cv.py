@@ -35,21 +35,17 @@ def main():
         shutil.copyfile(f"{run}/{name}", f"{OUT}/run001a_free_{name}")
     os.system(f"chmod -R u+w {OUT}")
 
-if __name__ == "__main__":
-    main()
-    peak_fixture()
-    free_spectrum_fixture()
 
 
 def peak_fixture():
     """Committed reference run of sac_peak.jl (statistical oracle for the peak path):
-    sac/peak/out_files/fermionic2/Np_01/A0_0.700/{t.in,in_peak.in,anneal.csv,sample.csv,accept_rate.csv}
+    sac/peak/out_files/fermionic2/Np_01/A0_0.700/{t.in,in_peak.in,anneal.csv,sample.csv,accept_rate.csv,sw000.csv}
     -> tests/golden/peak_f2/ (data only; the other committed peak runs were written by older versions of
     sac_peak.jl whose accept_rate.csv header and fixed +/- weight split differ from the current code)."""
     src = "/root/reference/sac/peak/out_files/fermionic2/Np_01/A0_0.700"
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "peak_f2")
     os.makedirs(out, exist_ok=True)
-    for name in ("t.in", "in_peak.in", "anneal.csv", "sample.csv", "accept_rate.csv"):
+    for name in ("t.in", "in_peak.in", "anneal.csv", "sample.csv", "accept_rate.csv", "sw000.csv"):
         shutil.copyfile(f"{src}/{name}", f"{out}/{name}")
     os.system(f"chmod -R u+w {out}")
     with open(f"{out}/in_peak.in") as f:          # keep the six parameter rows, drop the commentary
@@ -72,3 +68,26 @@ def free_spectrum_fixture():
         rows = f.readlines()[:6]
     with open(f"{out}/in_free.in", "w") as f:
         f.writelines(rows)
+
+
+def peak_cv_fixture():
+    """A committed reference run of sac_peak.jl whose schedule is short enough to be repeated in full by a test (statistical
+    oracle with the reference's OWN sweeps per Theta): cross_validation/out_files/bosonic_delta_peak/001a/peak/Np_01/A0_0.700/
+    {in_peak.in, anneal.csv, accept_rate.csv} -> tests/golden/peak_cv001a/ (its t.in is tests/golden/cv/t_001a.in)."""
+    src = f"{REF}/out_files/bosonic_delta_peak/001a/peak/Np_01/A0_0.700"
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "peak_cv001a")
+    os.makedirs(out, exist_ok=True)
+    for name in ("in_peak.in", "anneal.csv", "accept_rate.csv"):
+        shutil.copyfile(f"{src}/{name}", f"{out}/{name}")
+    os.system(f"chmod -R u+w {out}")
+    with open(f"{out}/in_peak.in") as f:
+        rows = f.readlines()[:6]
+    with open(f"{out}/in_peak.in", "w") as f:
+        f.writelines(rows)
+
+
+if __name__ == "__main__":
+    main()
+    peak_fixture()
+    free_spectrum_fixture()
+    peak_cv_fixture()

@@ -33,6 +33,9 @@ def main():
             edges = [ln.split(" - ", 1)[1] for ln in f if "Edge:" in ln]
         with open(os.path.join(out, "init_edges.txt"), "w") as f:
             f.writelines(edges)
+        if name == "hchain_single":          # the run's final spectra (statistical oracle for write_spec, edge:1514-1637)
+            for f in ("sw000_1.dat", "dw000_1.dat"):
+                shutil.copyfile(os.path.join(src, f), os.path.join(out, f))
         os.system(f"chmod -R u+w {out}")
 
 
