@@ -219,6 +219,16 @@ int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min);
 int sac_set_chains_per_wave(sac_handle_t *h, int32_t chains_per_wave);
 int sac_get_chains_per_wave(sac_handle_t *h, int32_t *last_used);
 
+/* Cross-validation scoring behind the boundary: what calc_cv.jl:29-58 computes from a GSAC.csv row
+ * (cross_val.jl:105-108), taken directly from the Gbar the chains hold -- no file round trip:
+ *   t = U_this Gbar (cv:106), y = U_other^T t (calc_cv.jl:37), chi2_v = sum_j ((y_j - G_other_j) sigma_inv_other_j)^2.
+ * U_this / U_other: the `cov` of this handle's t.in and of the OTHER half's, [n_tau][n_tau] row-major; G_other already in
+ * its eigenbasis (read_G!, free:123).  gbar_mean: NULL = the mean over this handle's chains, else n_tau doubles (e.g. the
+ * mean over all ranks).  chi2_mean: chi2_v of that mean Gbar (the quantity calc_cv.jl scores, not yet divided by N_tau);
+ * chi2_chain[n_chains] (may be NULL): chi2_v of every chain's own Gbar. */
+int sac_validation_chi2(sac_handle_t *h, const double *U_this, const double *U_other, const double *G_other,
+                        const double *sigma_inv_other, const double *gbar_mean, double *chi2_mean, double *chi2_chain);
+
 /* Parity / debug entry (no counterpart in the reference): evaluates an explicit proposal stream
  * on one chain of the free parameterisation (par = 1 or 3) -- what the reference's move loops do once the
  * indices, the new positions (in bounds) and the accept uniform are drawn (free:296-320, 354-380, 437-470).
@@ -338,6 +348,9 @@ typedef struct {
 } sac_edge_proposal_t;
 int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const sac_edge_proposal_t *props, int64_t n,
                     const double *w_new, int64_t n_w, double *chi2_new, int32_t *accepted);
+/* sac_validation_chi2 for an edge handle (cv:494-497 + calc_cv.jl:29-58) */
+int sac_edge_validation_chi2(sac_edge_t *h, const double *U_this, const double *U_other, const double *G_other,
+                             const double *sigma_inv_other, const double *gbar_mean, double *chi2_mean, double *chi2_chain);
 int sac_edge_set_move_log(sac_edge_t *h, int32_t chain, int64_t capacity);
 int sac_edge_get_move_log(sac_edge_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
 

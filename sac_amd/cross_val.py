@@ -19,7 +19,37 @@ def _append_gsac(path, theta, cov, gbar):
         f.write(",".join(jl_float(float(v)) for v in row) + "\n")
 
 
-def free_cv(rep, ab, in_file="in_free.in", **kw):
+def _fused_validation(s, validate_tin):
+    """Row f3 of SURVEY section 8: the validation chi^2 of calc_cv.jl:29-58 taken on the device from the chains' Gbar at
+    the end of every Theta stage (sac_validation_chi2), no GSAC.csv round trip.  Returns the hook's scorer: it appends
+    (Theta, chi2_v / N_tau) to s.validation and to <output_folder>/validation.csv."""
+    if validate_tin is None:
+        return None
+    from .tin import read_tin
+    td_o = read_tin(validate_tin) if isinstance(validate_tin, str) else validate_tin
+    s.validation = []
+    path = s.output_folder + "/validation.csv"
+    if s.is_root:
+        with open(path, "w") as f:
+            f.write("theta,chi2_val\n")
+
+    def score(theta, gbar_mean=None):
+        v = s.h.validation_chi2(s.td.cov, td_o, gbar_mean=gbar_mean) / s.td.n_tau
+        s.validation.append((_jl_round(theta, 8), v))
+        if s.is_root:
+            with open(path, "a") as f:
+                f.write(f"{jl_float(float(_jl_round(theta, 8)))},{jl_float(float(v))}\n")
+    return score
+
+
+def cv_score_fused(s_a, s_b):
+    """calc_cv.jl:82-107 from two fused runs: s_a validated against half b's data and s_b against half a's."""
+    va, vb = np.array(s_a.validation), np.array(s_b.validation)
+    n = min(len(va), len(vb))
+    return va[:n, 0], 0.5 * (va[:n, 1] + vb[:n, 1])
+
+
+def free_cv(rep, ab, in_file="in_free.in", validate_tin=None, **kw):
     """cv:6-144.  Returns the FreeSAC object (its output_folder holds GSAC.csv, anneal.csv, ...)."""
     s = FreeSAC.from_infile(in_file, **kw)
     G_folder = s.G_file                                             # row 5 holds the folder here (cv:14)
@@ -28,10 +58,10 @@ def free_cv(rep, ab, in_file="in_free.in", **kw):
     s.output_folder = base + "/%03i%s/free" % (rep, ab)             # cv:18
     if s.symm == 1 and s.kernel_type != "bosonic":
         s.output_folder += "_symm"                                  # cv:24-26
-    return _free_cv_run(s, in_file)
+    return _free_cv_run(s, in_file, validate_tin)
 
 
-def _free_cv_run(s, in_file=None):
+def _free_cv_run(s, in_file=None, validate_tin=None):
     if s.is_root:
         os.makedirs(s.output_folder, exist_ok=True)
         if in_file and os.path.exists(in_file):
@@ -51,17 +81,21 @@ def _free_cv_run(s, in_file=None):
     s.write_log("Equillibration Finished.")
     s.write_log("Beginning Main Anneal.")
 
+    score = _fused_validation(s, validate_tin)
+
     def dump(i, theta):
         g = s.mean_gbar()
         if s.is_root:
             _append_gsac(gsac, theta, s.td.cov, g)
+        if score is not None:                                       # the same quantity without the file (row f3)
+            score(theta, gbar_mean=g if s.comm is not None else None)
 
     s.main_anneal(on_stage=dump)                                    # cv:98-140
     s.write_log("Main Anneal Finished.")
     return s
 
 
-def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, **kw):
+def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, validate_tin=None, **kw):
     """cv:147-312: as free_cv for the peak parameterisation (initial sampling, then the anneal with the
     GSAC dump)."""
     s = PeakSAC.from_infile(in_file, A_0_in=A_0, N_p_in=N_p, **kw)
@@ -100,12 +134,15 @@ def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, **kw):
             g, n = tot[:-1], tot[-1]
         if s.is_root:
             _append_gsac(gsac, theta, s.td.cov, g / n)
+        if score is not None:
+            score(theta, gbar_mean=(g / n) if s.comm is not None else None)
 
+    score = _fused_validation(s, validate_tin)
     s.run_anneal(s.theta_0, on_stage=dump)
     return s
 
 
-def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, **kw):
+def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, validate_tin=None, **kw):
     """cv:315-509: equilibration, then the full Theta ladder (no stop rule) with one GSAC row per stage."""
     import math
     s = EdgeSAC.from_infile(in_file, A_c_in=A_c, A_r_in=A_r, p_in=p, **kw)
@@ -125,6 +162,7 @@ def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, **kw):
     s.write_log("Beginning Initialization.", "w")
     s.init_outfiles()
     s.initialize()
+    score = _fused_validation(s, validate_tin)
     s.write_log("Running Equillibration Sweeps.")
     s.run_bins(5 * s.anneal_steps, s.bins, s.theta_0)               # cv:466-467
     s.write_res(0, s.theta_0)
@@ -145,6 +183,8 @@ def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, **kw):
             g = tot[:-1] / tot[-1]
         if s.is_root:
             _append_gsac(gsac, theta, s.td.cov, g)
+        if score is not None:
+            score(theta, gbar_mean=g if s.comm is not None else None)
         theta /= s.f_anneal
         s.chi2_anneal[i - 1] = s.res["chi2_res"][1]
     s.write_log("Main Anneal Finished.")

@@ -13,6 +13,7 @@
 #include "../../include/sac_hip.h"
 #include "edge_sweep.h"
 #include "table_build.h"
+#include "cv_score.h"
 
 using namespace sacdev;
 
@@ -1128,6 +1129,24 @@ extern "C" int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const
     HIP_TRY(hipFree(dW));
     HIP_TRY(hipFree(dC));
     HIP_TRY(hipFree(dAcc));
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_validation_chi2(sac_edge_t *h, const double *U_this, const double *U_other, const double *G_other,
+                                        const double *sigma_inv_other, const double *gbar_mean, double *chi2_mean, double *chi2_chain)
+{
+    if (!h || !U_this || !U_other || !G_other || !sigma_inv_other)
+        return efail(SAC_E_INVALID, "sac_edge_validation_chi2: null argument");
+    if (!h->gbar_set) return efail(SAC_E_STATE, "sac_edge_validation_chi2: no Gbar yet (sac_edge_init_gbar)");
+    const size_t nt = (size_t)h->cfg.n_tau;
+    for (size_t j = 0; j < nt; ++j)
+        if (!std::isfinite(G_other[j]) || !std::isfinite(sigma_inv_other[j]))
+            return efail(SAC_E_INVALID, "sac_edge_validation_chi2: non-finite G or sigma_inv at tau index %zu", j);
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(cv_score_run(h->stream, h->dGbar, SAC_MAX_N_TAU, h->cfg.n_chains, h->cfg.n_tau, U_this, U_other, G_other,
+                         sigma_inv_other, gbar_mean, chi2_mean, chi2_chain));
     return SAC_OK;
 }
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "sac_edge_get_move_log",
     "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
-    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_replay_peak", "sac_edge_replay",
+    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -143,6 +143,8 @@ def load_library():
     L.sac_copy_chain.argtypes = [vp, C.c_int32, C.c_int32]
     L.sac_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_get_chain_chi2.argtypes = [vp, dp, dp]
+    L.sac_validation_chi2.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
+    L.sac_edge_validation_chi2.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
     L.sac_replay_peak.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, vp]
     L.sac_build_table.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_build_table_noalloc.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
@@ -347,6 +349,19 @@ class SacHandle:
         self._check(self.L.sac_replay(self.h, chain, float(theta), props.ctypes.data, n, _dp(c2), acc.ctypes.data))
         return c2, acc
 
+    def validation_chi2(self, cov_this, td_other, gbar_mean=None, per_chain=False):
+        """calc_cv.jl:29-58 on the device: chi2_v (not divided by N_tau) of the chain-mean Gbar (or of gbar_mean) against the
+        other half's data td_other; with per_chain also every chain's own."""
+        U_t = np.ascontiguousarray(cov_this, dtype=np.float64)
+        U_o = np.ascontiguousarray(td_other.cov, dtype=np.float64)
+        G_o = np.ascontiguousarray(td_other.G, dtype=np.float64)
+        s_o = np.ascontiguousarray(td_other.sigma_inv, dtype=np.float64)
+        gm = None if gbar_mean is None else np.ascontiguousarray(gbar_mean, dtype=np.float64)
+        out = C.c_double(0.0)
+        chains = np.empty(self.cfg.n_chains) if per_chain else None
+        self._check(self.L.sac_validation_chi2(self.h, _dp(U_t), _dp(U_o), _dp(G_o), _dp(s_o), _dp(gm), C.byref(out), _dp(chains)))
+        return (out.value, chains) if per_chain else out.value
+
     def replay_peak(self, props, theta, chain=0):
         """props: array of PEAK_PROPOSAL records.  Returns (chi2_new[n], accepted[n])."""
         props = np.ascontiguousarray(props, dtype=PEAK_PROPOSAL)
@@ -514,6 +529,19 @@ class SacEdgeHandle:
         c, m = C.c_double(), C.c_double()
         self._check(self.L.sac_edge_get_gbar(self.h, chain, _dp(g), C.byref(c), C.byref(m)))
         return g, c.value, m.value
+
+    def validation_chi2(self, cov_this, td_other, gbar_mean=None, per_chain=False):
+        """calc_cv.jl:29-58 on the device: chi2_v (not divided by N_tau) of the chain-mean Gbar (or of gbar_mean) against the
+        other half's data td_other; with per_chain also every chain's own."""
+        U_t = np.ascontiguousarray(cov_this, dtype=np.float64)
+        U_o = np.ascontiguousarray(td_other.cov, dtype=np.float64)
+        G_o = np.ascontiguousarray(td_other.G, dtype=np.float64)
+        s_o = np.ascontiguousarray(td_other.sigma_inv, dtype=np.float64)
+        gm = None if gbar_mean is None else np.ascontiguousarray(gbar_mean, dtype=np.float64)
+        out = C.c_double(0.0)
+        chains = np.empty(self.cfg.n_chains) if per_chain else None
+        self._check(self.L.sac_edge_validation_chi2(self.h, _dp(U_t), _dp(U_o), _dp(G_o), _dp(s_o), _dp(gm), C.byref(out), _dp(chains)))
+        return (out.value, chains) if per_chain else out.value
 
     def replay(self, props, w_new, theta, chain=0):
         """props: array of EDGE_PROPOSAL records, w_new: the new frequencies they index.  Returns (chi2_new[n], accepted[n])."""
