@@ -11,6 +11,10 @@ cross_val.jl:514-531): run from a directory holding in_free.in / in_peak.in / in
          Julia process per parameter point, run_cv.sh:5-9 / qsub_files/edge/submit.sh:25-51)
     python -m torch.distributed.run --nproc-per-node G -m sac_amd cv-all REP_FIRST REP_LAST [free,peak,edge]
         (replicas x halves x parameterisations round-robin over the G GPUs; in-files in the working directory)
+    python -m torch.distributed.run --nproc-per-node G -m sac_amd scan edge p|A_c|A_r V_0 DELTA N [A_c A_r p]
+    python -m torch.distributed.run --nproc-per-node G -m sac_amd scan peak A_0 V_0 DELTA N [N_p]
+        (the parameter scans of qsub_files/edge/submit.sh:25-51 and qsub_files/peak/qsub_a0_scan.sh: value = V_0 + DELTA (i - 1),
+         one whole GPU per scan point, round-robin; the trailing values fix the other command-line parameters)
 """
 import argparse
 import sys
@@ -18,7 +22,7 @@ import sys
 
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m sac_amd")
-    ap.add_argument("program", choices=["free", "peak", "edge", "cv", "cv-all"])
+    ap.add_argument("program", choices=["free", "peak", "edge", "cv", "cv-all", "scan"])
     ap.add_argument("args", nargs="*")
     ap.add_argument("--chains", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
@@ -57,6 +61,33 @@ def main(argv=None):
         finally:
             if world > 1:
                 dist.destroy_process_group()
+    if a.program == "scan":
+        import os
+        from .scan import best_point, run_scan_partition, scan_units, scan_values
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        kw["device"] = int(os.environ.get("LOCAL_RANK", str(a.device)))
+        if len(a.args) < 5:
+            ap.error("scan needs: edge|peak AXIS V_0 DELTA N [fixed values]")
+        prog, axis = a.args[0], a.args[1]
+        values = scan_values(float(a.args[2]), float(a.args[3]), int(a.args[4]))
+        rest = [float(x) for x in a.args[5:]]
+        names = ("A_c", "A_r", "p") if prog == "edge" else ("N_p",)
+        fixed = {n: v for n, v in zip(names, rest) if n != axis}
+        units = scan_units(prog, axis, values, **fixed)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(kw["device"])
+            dist.init_process_group(a.backend if a.backend != "nccl" else "nccl",
+                                    **({"device_id": torch.device("cuda", kw["device"])} if a.backend == "nccl" else {}))
+        results = run_scan_partition(units, rank, world, **kw)
+        if rank == 0:
+            for u in units:
+                print(dict(u[1]), results[u])
+            print("best:", dict(best_point(results)[0][1]))
+        if world > 1:
+            dist.destroy_process_group()
+        return results
     if a.program == "cv-all":
         import os
         from .cross_val import cv_units, run_cv_partition

@@ -223,14 +223,10 @@ def partition_units(units, rank, world):
     return list(units[rank::world])
 
 
-def run_cv_partition(units, rank=0, world=1, runner=None, gather=None, **kw):
-    """Runs this rank's share of `units` and returns, on every rank, {unit: output folder} for all units.
-    runner(unit, **kw) -> output folder; default = free_cv / peak_cv / edge_cv on this rank's GPU.
-    gather(obj) -> list of every rank's obj (default: torch.distributed.all_gather_object when world > 1)."""
-    if runner is None:
-        def runner(unit, **k):
-            prm, rep, ab = unit
-            return {"free": free_cv, "peak": peak_cv, "edge": edge_cv}[prm](rep, ab, **k).output_folder
+def run_partition(units, rank, world, runner, gather=None, **kw):
+    """Deals `units` round-robin to the ranks, runs this rank's share with runner(unit, **kw) and returns, on every
+    rank, {unit: result} for all units.  gather(obj) -> list of every rank's obj (default:
+    torch.distributed.all_gather_object when world > 1).  Shared by the cross-validation units and the scans (scan.py)."""
     mine = {}
     for unit in partition_units(units, rank, world):
         mine[unit] = runner(unit, **kw)
@@ -248,8 +244,18 @@ def run_cv_partition(units, rank=0, world=1, runner=None, gather=None, **kw):
         merged.update(part)
     missing = [u for u in units if u not in merged]
     if missing:
-        raise RuntimeError(f"cross-validation units without a result: {missing}")
+        raise RuntimeError(f"units without a result: {missing}")
     return merged
+
+
+def run_cv_partition(units, rank=0, world=1, runner=None, gather=None, **kw):
+    """Runs this rank's share of `units` and returns, on every rank, {unit: output folder} for all units.
+    runner(unit, **kw) -> output folder; default = free_cv / peak_cv / edge_cv on this rank's GPU."""
+    if runner is None:
+        def runner(unit, **k):
+            prm, rep, ab = unit
+            return {"free": free_cv, "peak": peak_cv, "edge": edge_cv}[prm](rep, ab, **k).output_folder
+    return run_partition(units, rank, world, runner, gather, **kw)
 
 
 def cv_curves(folders, tin_folder, params=("free", "peak", "edge")):

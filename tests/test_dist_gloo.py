@@ -151,3 +151,48 @@ def test_cv_units_round_robin_over_two_ranks(tmp_path):
         n = min(len(v), exp.shape[1])
         np.testing.assert_allclose(th[:n], exp[0][:n], rtol=1e-9)
         np.testing.assert_allclose(v[:n], exp[rep][:n], rtol=1e-9)
+
+
+def _scan_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sac_amd.scan import best_point, run_scan_partition, scan_units, scan_values
+    ran = []
+
+    def runner(unit, **kw):
+        # stands in for a complete sac_edge run on this rank's GPU at that parameter point
+        prog, par = unit
+        par = dict(par)
+        ran.append(par["p"])
+        return dict(folder=f"out/p_{par['p']:.3f}", chi2_avg=(par["p"] - 0.4) ** 2 + 1.0, theta_opt=0.1)
+
+    units = scan_units("edge", "p", scan_values(0.3, 0.1, 5), A_c=0.0, A_r=0.5)     # qsub_p_scan.sh with N_p = 5
+    res = run_scan_partition(units, rank, world, runner=runner)
+    best = best_point(res)
+    out[rank] = dict(ran=ran, n=len(res), best=dict(best[0][1])["p"], keys=[dict(u[1])["p"] for u in units])
+    dist.destroy_process_group()
+
+
+def test_scan_points_round_robin_over_two_ranks():
+    """Parameter-scan points (qsub_files/edge/qsub_p_scan.sh:13-19: p = p_0 + delta_p (task - 1)) as whole-GPU units."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_scan_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["keys"] == [0.3, 0.4, 0.5, 0.6, 0.7]
+    assert r0["ran"] == [0.3, 0.5, 0.7] and r1["ran"] == [0.4, 0.6]            # disjoint, covering, alternating
+    assert r0["n"] == r1["n"] == 5 and r0["best"] == r1["best"] == 0.4         # every rank learns every point
+
+
+def test_theta_scan_points_follow_the_reference_ladder():
+    from sac_amd.scan import scan_units, theta_scan_points
+    pts = theta_scan_points(1.0, 0.1)                                          # edge:1805-1809, f_scan = 1.15
+    assert len(pts) == 17 and pts[0] == 1.0 and pts[-1] > 0.1 > pts[-1] / 1.15
+    assert np.allclose(np.array(pts[:-1]) / np.array(pts[1:]), 1.15)
+    with pytest.raises(ValueError):
+        scan_units("peak", "p", [0.1])
+    u = scan_units("peak", "A_0", [0.5, 0.6], N_p=1)
+    assert [dict(x[1]) for x in u] == [{"A_0": 0.5, "N_p": 1}, {"A_0": 0.6, "N_p": 1}]

@@ -108,3 +108,54 @@ def test_two_rank_drivers_equal_single_process(tmp_path):
     assert os.path.exists(tmp_path / "edge2" / "sw001_1.dat") and os.path.exists(tmp_path / "peak2" / "sw001.csv")
     two, one = (np.loadtxt(tmp_path / d / "sw001.csv", delimiter=",", skiprows=1) for d in ("free2", "free1"))
     np.testing.assert_allclose(two, one, rtol=1e-11, atol=0)         # the merge adds the ranks' sums in another order
+
+
+def _theta_scan(rank, world, folder, gather=None):
+    from sac_amd.edge import EdgeSAC
+    from sac_amd.scan import sharded_theta_scan
+    s = EdgeSAC.from_infile(f"{GOLD}/edge/hchain_single/in_edge.in", n_chains=16, seed=41)
+    s.G_file, s.output_folder, s.d_omega = f"{GOLD}/edge/hchain_single/t.in", folder, 1e-4
+    s.anneal_steps, s.sample_steps, s.bins, s.f_anneal = 400, 150, 10, 1.25
+    os.makedirs(folder, exist_ok=True)
+    s.write_log("start", "w")
+    s.init_outfiles()
+    s.initialize()
+    s.run_bins(5 * s.anneal_steps, s.bins, s.theta_0)
+    rows = sharded_theta_scan(s, theta_1=2.0, theta_2=0.8, rank=rank, world=world, gather=gather)
+    s.h.close()
+    return rows
+
+
+def _scan_worker(rank, world, port, base, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out[rank] = _theta_scan(rank, world, f"{base}/scan2_rank{rank}")
+    dist.destroy_process_group()
+
+
+def test_theta_scan_points_sharded_over_two_ranks(tmp_path):
+    """anneal_and_scan's Theta points (edge:1783-1846) dealt round-robin to two ranks (scan.sharded_theta_scan) against the
+    sequential walk of one process: the same ladder, every point sampled by exactly one rank, every rank learns all rows,
+    and <chi^2> at each point agrees with the sequential walk within the runs' own error bars (each point is an
+    equilibrium sample at its own Theta: that is what makes the sharding legitimate)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_scan_worker, args=(2, port, str(tmp_path), out), nprocs=2, join=True)
+    seq = _theta_scan(0, 1, str(tmp_path / "scan1"))
+    assert out[0] == out[1] and list(out[0]) == list(seq) == list(range(1, len(seq) + 1)) and len(seq) == 7
+    for i, row in seq.items():
+        two = out[0][i]
+        assert two["theta"] == pytest.approx(row["theta"], rel=1e-12)
+        err = np.hypot(row["chi2_sigma"], two["chi2_sigma"])
+        print(i, row["theta"], row["chi2_avg"], two["chi2_avg"], err)
+        assert abs(two["chi2_avg"] - row["chi2_avg"]) < 5 * err + 0.03 * row["chi2_avg"]
+        assert abs(two["edge"] - row["edge"]) < 0.01
+    # a point's files are written by the rank that sampled it: odd points by rank 0, even ones by rank 1
+    for i in seq:
+        owner = (i - 1) % 2
+        assert os.path.exists(tmp_path / f"scan2_rank{owner}" / f"sw{i:03d}_1.dat")
+        assert not os.path.exists(tmp_path / f"scan2_rank{1 - owner}" / f"sw{i:03d}_1.dat")
