@@ -48,9 +48,9 @@ def write_tin(path, beta, n_boot, norm, tau, G, sigma_bar, eig_sigma, eigvecs):
     """make_tin_zeroT.jl:143-153."""
     n = len(tau)
     with open(path, "w") as f:
-        f.write(f"{beta!r} {float(n)!r} {float(n_boot)!r} {norm!r}\n")
+        f.write(f"{float(beta)!r} {float(n)!r} {float(n_boot)!r} {float(norm)!r}\n")
         for i in range(n):
-            f.write(f"{tau[i]!r} {G[i]!r} {sigma_bar[i]!r} {eig_sigma[i]!r}\n")
+            f.write(f"{float(tau[i])!r} {float(G[i])!r} {float(sigma_bar[i])!r} {float(eig_sigma[i])!r}\n")
         for j in range(n):
             f.write(f"{j + 1}\n")
             for v in eigvecs[:, j]:
