@@ -32,6 +32,9 @@ SWEEPS_PER_STEP = 400
 THETA = 1.0
 SEED = 12345
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# measured gather-only ceiling for THIS workload's (cache-resident, concentrated) column distribution:
+# profiles/r02_gather_probe.txt, tools/gather_probe --positions on the positions of a tuned run at this shape
+GATHER_CEILING_GBS = 17368.0
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4           # peak engine clock
 # a wave64 VALU instruction occupies its SIMD for one "quad-cycle" (4 clocks: 16 lanes per clock); SQ_ACTIVE_INST_VALU
@@ -299,9 +302,12 @@ def main():
                      "traffic_note": "bytes per launch beyond L2, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json",
                      "hbm_frac": None if traffic is None else traffic / per_launch_s / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_GBps": alg_gbps, "algorithmic_over_hbm_peak": alg_gbps / HBM_PEAK_GBS,
+                     "gather_ceiling_GBps": GATHER_CEILING_GBS, "algorithmic_over_gather_ceiling": alg_gbps / GATHER_CEILING_GBS,
+                     "gather_ceiling_source": "profiles/r02_gather_probe.txt (gather-only probe on the sampler's own column "
+                                              "distribution, 48.8 MiB table)",
                      "note": "table is cache resident: the algorithmic gather rate exceeds the HBM peak and is not a "
                              "roofline fraction; see hbm_regime for the HBM-bound shapes",
-                     "kernel": "free_stage_kernel<1,false,true,false>", "launches": launches,
+                     "kernel": "free_stage_kernel<1,false,true,false>", "chains_per_wave": h.chains_per_wave(), "launches": launches,
                      "avg_launch_ms": per_launch_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes / n_l,
                      "pmc_source": None if pmc is None else pmc.get("source")})
         wi0, _, win0 = h.get_state(0)

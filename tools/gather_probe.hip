@@ -3,10 +3,17 @@
 // per CU -- the same shape as free_stage_kernel's K-column gathers, with all arithmetic removed.
 // Also the calibration run for FETCH_SIZE on this access width (known byte count).
 //   gather_probe <table_MiB> <rows_per_wave> [waves]
+//   gather_probe --positions <file> <rows_per_wave>
+//       the sampler's OWN column distribution: <file> (tools/dump_positions.py) holds, for every chain of a tuned run at the
+//       bench shape, its delta positions and its tuned single-move window; wave c then gathers what chain c's single moves
+//       gather -- the column of a random delta of the chain and the column a window shift away (free:283-302) -- with the
+//       chain's positions in LDS as in the sampler.  This is the gather ceiling for the concentrated, cache-resident access
+//       pattern of BASELINE configs[1] (a uniform-random probe is not: the sampler beats it).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
 
 constexpr int DEPTH = 16;
 
@@ -30,8 +37,86 @@ __global__ void __launch_bounds__(256) gather_rows(const double *table, uint32_t
     if (acc == 123.456) out[wave] = acc;                           // keep the loads alive
 }
 
+// pairs (new, old) as chain `wave`'s single-delta proposals request them
+__global__ void __launch_bounds__(256) gather_pairs(const double *table, uint32_t n_rows, const uint32_t *pos, const double *window,
+                                                    int n_omega, int iters, double *out)
+{
+    __shared__ uint32_t s_pos[4][2048];
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t wl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = lane; i < n_omega; i += 64) s_pos[wl][i] = pos[(size_t)wave * n_omega + i];
+    const double w = window[wave];
+    uint32_t s = wave * 2654435761u + 12345u;
+    double acc = 0.0;
+    constexpr int PAIRS = DEPTH / 2;
+    for (int it = 0; it < iters; it += DEPTH) {
+        double v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < PAIRS; ++d) {
+            s = s * 1664525u + 1013904223u;
+            const uint32_t k = (uint32_t)(((uint64_t)s * (uint32_t)n_omega) >> 32);
+            s = s * 1664525u + 1013904223u;
+            const int shift = 1 + (int)((double)(s >> 8) * (1.0 / 16777216.0) * w);
+            const int old = (int)s_pos[wl][k];
+            int nw = (s & 1u) ? old + shift : old - shift;
+            nw = nw < 0 ? 0 : (nw >= (int)n_rows ? (int)n_rows - 1 : nw);
+            const uint32_t r_old = __builtin_amdgcn_readfirstlane((uint32_t)old), r_new = __builtin_amdgcn_readfirstlane((uint32_t)nw);
+            v[2 * d] = table[(size_t)r_new * 64 + lane];
+            v[2 * d + 1] = table[(size_t)r_old * 64 + lane];
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) acc += v[d];
+    }
+    if (acc == 123.456) out[wave] = acc;
+}
+
+static int run_positions(const char *path, int iters)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", path); return 1; }
+    int32_t hdr[4];                                  // chains, n_omega, n_rows, reserved
+    if (fread(hdr, sizeof(hdr), 1, f) != 1) return 1;
+    const int waves = hdr[0], n_omega = hdr[1];
+    const uint32_t n_rows = (uint32_t)hdr[2];
+    uint32_t *h_pos = (uint32_t *)malloc((size_t)waves * n_omega * 4);
+    double *h_win = (double *)malloc((size_t)waves * 8);
+    if (fread(h_pos, 4, (size_t)waves * n_omega, f) != (size_t)waves * n_omega) return 1;
+    if (fread(h_win, 8, (size_t)waves, f) != (size_t)waves) return 1;
+    fclose(f);
+    if (n_omega > 2048 || waves % 4) { fprintf(stderr, "shape\n"); return 1; }
+    double *table, *out, *d_win;
+    uint32_t *d_pos;
+    hipMalloc(&table, (size_t)n_rows * 512);
+    hipMalloc(&out, waves * sizeof(double));
+    hipMalloc(&d_pos, (size_t)waves * n_omega * 4);
+    hipMalloc(&d_win, (size_t)waves * 8);
+    hipMemset(table, 0, (size_t)n_rows * 512);
+    hipMemcpy(d_pos, h_pos, (size_t)waves * n_omega * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_win, h_win, (size_t)waves * 8, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int it = (iters / DEPTH) * DEPTH;
+    gather_pairs<<<waves / 4, 256>>>(table, n_rows, d_pos, d_win, n_omega, it / 10, out);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    gather_pairs<<<waves / 4, 256>>>(table, n_rows, d_pos, d_win, n_omega, it, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)waves * it * 512.0;
+    double wmean = 0;
+    for (int i = 0; i < waves; ++i) wmean += h_win[i] / waves;
+    printf("{\"pattern\": \"sampler positions + window shift\", \"table_MiB\": %.1f, \"rows\": %u, \"waves\": %d, \"rows_per_wave\": %d, "
+           "\"mean_window\": %.1f, \"bytes\": %.0f, \"ms\": %.3f, \"GBps\": %.1f}\n", n_rows * 512.0 / 1048576.0, n_rows, waves, it, wmean,
+           bytes, ms, bytes / ms / 1e6);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 2 && !strcmp(argv[1], "--positions")) return run_positions(argv[2], argc > 3 ? atoi(argv[3]) : 200000);
     const double mib = argc > 1 ? atof(argv[1]) : 49.0;
     const int iters = argc > 2 ? atoi(argv[2]) : 200000;
     const int waves = argc > 3 ? atoi(argv[3]) : 4096;
