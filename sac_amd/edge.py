@@ -230,8 +230,10 @@ class EdgeSAC:
 
     def __init__(self, N_e, N_c, omega_0, omega_m, d_omega_h, d_omega, p, A_c, A_r, theta_0, f_anneal, N_anneal,
                  a_criterion, anneal_steps, sample_steps, bins, G_file, output_folder, fix_edge, kernel_type, mode,
-                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None):
+                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None, spread_sampling=False):
         self.comm = comm
+        # no counterpart in the one-chain reference: the final sampling's sweeps per bin are shared out over all chains
+        self.spread_sampling = bool(spread_sampling)
         self.is_root = comm is None or comm.rank == 0
         self.N_e, self.N_c = int(N_e), int(N_c)
         self.omega_0, self.omega_m, self.d_omega_h, self.d_omega = float(omega_0), float(omega_m), float(d_omega_h), float(d_omega)
@@ -522,9 +524,14 @@ class EdgeSAC:
         self.write_log("Final Anneal Finished.")
         self.write_log("Beginning Final Sampling.")
         bins = 10
-        self.run_bins(self.sample_steps, bins, theta_opt)
+        steps = self.sample_steps
+        if self.spread_sampling:
+            from .free import MIN_SPREAD_STEPS
+            total = self.n_chains * (1 if self.comm is None else self.comm.world)
+            steps = max(MIN_SPREAD_STEPS, -(-self.sample_steps // total))
+        self.run_bins(steps, bins, theta_opt)
         for rl in self.prob.rls:
-            self.write_spec(0, bins * self.sample_steps, rl)
+            self.write_spec(0, bins * steps, rl)
         self._sample_row(0, theta_opt, with_cont=True)
         self.write_log("Final Sampling Finished.")
         return theta_opt

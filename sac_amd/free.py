@@ -118,6 +118,9 @@ def _jl_round(x, digits):
     return np.round(x * p) / p
 
 
+MIN_SPREAD_STEPS = 20       # spread_sampling: a chain's share of the final sampling is never shorter than this
+
+
 class FreeSAC:
     """The reference's SAC struct + schedule functions for the `free` parameterisation, with the
     fixed-Theta stages (adjust_windows, sample) running on the GPU behind the C ABI.
@@ -128,7 +131,7 @@ class FreeSAC:
 
     def __init__(self, par, N_omega, omega_0, omega_m, d_omega, d_omega_h, theta_0, f_anneal, f_final,
                  a1, a2, N_anneal, anneal_steps, sample_steps, G_file, output_folder, symm, kernel_type,
-                 n_chains=1, seed=0, tol=1e-3, device=0, comm=None, timedata=None):
+                 n_chains=1, seed=0, tol=1e-3, device=0, comm=None, timedata=None, spread_sampling=False, device_tables=False):
         self.par, self.N_omega = int(par), int(N_omega)
         self.omega_0, self.omega_m, self.d_omega, self.d_omega_h = float(omega_0), float(omega_m), float(d_omega), float(d_omega_h)
         self.theta_0, self.f_anneal, self.f_final = float(theta_0), float(f_anneal), float(f_final)
@@ -139,6 +142,10 @@ class FreeSAC:
         self.tol = tol                                              # free:27
         self.n_chains, self.seed, self.device, self.comm = n_chains, seed, device, comm
         self.timedata = timedata
+        # no counterpart in the one-chain reference: the final sampling's sample_steps sweeps are shared out over all chains
+        # (each runs ceil(sample_steps / chains) sweeps, at least MIN_SPREAD_STEPS); equilibration stages are not shortened
+        self.spread_sampling = bool(spread_sampling)
+        self.device_tables = bool(device_tables)                    # K table built on the GPU (sac_build_table, row f1)
         self.chi2_anneal = np.zeros(self.N_anneal)                  # free:160
         self.h = None
         self.is_root = comm is None or comm.rank == 0
@@ -172,7 +179,7 @@ class FreeSAC:
                                 par=self.par, symm=self.symm, kernel_type=self.kernel_type)
         offset = 0 if self.comm is None else self.comm.rank * self.n_chains
         self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, chain_offset=offset,
-                                       device=self.device)
+                                       device=self.device, device_tables=self.device_tables)
         self._merge()
         return self
 
@@ -320,8 +327,12 @@ class FreeSAC:
             self.sample(steps, theta)
         n_final = 1 if self.a1 == self.a2 else 20
         theta = theta_opt
+        steps = self.sample_steps
+        if self.spread_sampling:
+            total = self.n_chains * (1 if self.comm is None else self.comm.world)
+            steps = max(MIN_SPREAD_STEPS, -(-self.sample_steps // total))
         for n in range(1, n_final + 1):
-            self.sample(self.sample_steps, theta)
+            self.sample(steps, theta)
             a = (self.sampled_chi2 - self.chi2_min) / np.sqrt(2 * self.chi2_min)   # free:1128
             if self.is_root:
                 with open(self.sample_file, "a") as f:              # free:1131-1133
