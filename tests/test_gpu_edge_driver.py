@@ -84,12 +84,14 @@ def test_edge_anneal_follows_reference_run(tmp_path):
 def test_edge_reference_schedule_z_test(tmp_path):
     """The first 8 points of the reference's own Theta ladder with the reference's own sweeps per stage (equilibration
     5 x 600 x 20, then 20 bins of 600 (1 - i / 48) sweeps per Theta; only the kernel grid is 10 x coarser) on 32 chains.  The
-    reference prints the error bars of its own run (sigma of the bin means: chi2_sigma, edge_R_sigma, n0_R_sigma), so with
-    m, s the mean and scatter of the chains' stage averages
-        z = (m - ref) / sqrt(s^2 / 32 + sigma_ref^2)
-    is of order one if both sample the same distribution.  Required: |z| < 4.5 for <chi^2>, the edge location and n0 / N_e at
-    every Theta (measured maxima 2.4, 3.4, 1.9; the reference's bins are correlated for the slow edge mode, which makes its
-    sigma an underestimate and the edge z-scores the largest) and a mean z within +-1.5."""
+    reference's anneal.csv holds ONE chain's stage averages; a GPU chain's stage average is a draw from the same distribution
+    if the samplers agree, so with m, s the mean and scatter over the 32 GPU chains
+        z = (ref - m) / (s sqrt(1 + 1/32))
+    is standard normal -- for <chi^2>, the edge location and n0 / N_e.  (The error bars the reference prints are the scatter of
+    its bins within one run; the edge location is a slow mode and the run-to-run scatter is several times larger, which is why
+    the chains' own scatter is the yardstick: tools/edge_full_check.py, profiles/r02_edge_full_anneal_check.txt, does the same
+    over the reference's complete first anneal: 120 stages, max |z| 2.3, rms 0.67.)  Required: |z| < 4 at every Theta and a
+    mean z within +-1.5 for each of the three observables."""
     n_chains, n_pts = 32, 8
     s = EdgeSAC.from_infile(f"{REF}/in_edge.in", n_chains=n_chains, seed=3)
     s.G_file = f"{REF}/t.in"
@@ -115,10 +117,10 @@ def test_edge_reference_schedule_z_test(tmp_path):
                                       ("edge", 5, 9, [p["edge_res"][1, 0] for p in per]),
                                       ("n0", 7, 11, [p["n0_res"][1, 0] for p in per])):
             v = np.array(vals)
-            zs[name].append((v.mean() - rr[col]) / np.sqrt(v.var(ddof=1) / n_chains + rr[scol] ** 2))
+            zs[name].append((rr[col] - v.mean()) / (v.std(ddof=1) * np.sqrt(1 + 1 / n_chains)))
         theta /= s.f_anneal
     for name, z in zs.items():
         z = np.array(z)
         print(name, "z", np.round(z, 2))
-        assert np.abs(z).max() < 4.5, (name, z)
+        assert np.abs(z).max() < 4.0, (name, z)
         assert abs(z.mean()) < 1.5, (name, z.mean())

@@ -93,15 +93,15 @@ elif what == "edge":
     first = lambda a: a[1:1 + np.argmax(np.diff(a[1:, 0]) < 0)] if (np.diff(a[1:, 0]) < 0).any() else a[1:]   # noqa: E731
     r1, g1 = first(ref), first(got)
     n = min(len(r1), len(g1))
-    # <chi^2>: the reference's own error bar and ours (sigma of the bin means, chain-averaged) in quadrature
-    z = (g1[:n, 3] - r1[:n, 3]) / np.sqrt(r1[:n, 4] ** 2 + (g1[:n, 4] ** 2) / chains)
+    # (the chain-by-chain comparison of <chi^2>(Theta) with the reference's single chain is tools/edge_full_check.py: the error bar
+    # the reference prints is the scatter of its bins, far below the run-to-run scatter of the slow edge mode)
     rs = np.genfromtxt(f"{REF}/sample.csv", delimiter=",", skip_header=1)
     gs = np.genfromtxt(os.path.join(s.output_folder, "sample.csv"), delimiter=",", skip_header=1)
     out = {"run": "sac/edge hchain_beta2048_single, full reference schedule", "chains": chains, "spread_sampling": spread,
            "d_omega": s.d_omega, "gpu_seconds": phases, "gpu_total_s": round(time.time() - t_all, 1),
            "reference_log_seconds": {"initialization": 3.7, "equilibration": 5.32, "main_anneal": 32.88, "final_anneal": 24.95,
                                      "final_sampling": 5.37, "note": "one chain, unknown CPU"},
-           "anneal_points_first_pass": [len(g1), len(r1)], "chi2_z_max": float(np.abs(z).max()), "chi2_z_rms": float(np.sqrt((z ** 2).mean())),
+           "anneal_points_first_pass": [len(g1), len(r1)],
            "chi2_ratio_last": float(g1[n - 1, 3] / r1[n - 1, 3]),
            "theta_opt": [float(theta_opt), float(rs[1])], "chi2_avg_final": [float(gs[3]), float(rs[3])], "edge_final": [float(gs[5]), float(rs[5])]}
 print(json.dumps(out))
