@@ -68,6 +68,72 @@ def bench_free2(chains, d_omega=1e-4, n_omega=2000, sweeps=100):
             "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9, "wall_s": dt}
 
 
+def bench_free_hbm(chains, d_omega=1e-5, n_omega=2000, sweeps=100):
+    """sac/free par=1 at bench.py's hbm_regime shapes: N_tau=64, 2000 deltas, 10^6+1 (d_omega=1e-5) or 4*10^6+1
+    (d_omega=2.5e-6) column table built on the device; same stage sequence as bench.py's hbm_regime (for the PMC passes)."""
+    from sac_amd.free import FreeProblem
+    td = synthetic_timedata(n_tau=64, seed=12345)
+    prob = FreeProblem(td, n_omega, 0.0, 10.0, d_omega, par=1, kernel_type="bosonic")
+    h = prob.make_handle(n_chains=chains, seed=12345, device_tables=True)
+    h.adjust_windows(200, 1.0)
+    h.sample(sweeps, 1.0)
+    s0 = h.stats()
+    kms, nl = 0.0, 0
+    for _ in range(2):
+        h.sample(sweeps, 1.0)
+        s1 = h.stats()
+        kms += s1.last_kernel_ms
+        nl += s1.last_kernel_launches
+    cols = s1.columns_gathered - s0.columns_gathered
+    return {"workload": f"sac/free bosonic, N_tau=64, {n_omega} deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), {chains} chains, Theta=1",
+            "chain_sweeps_per_s": (s1.sweeps - s0.sweeps) / (kms / 1e3), "accepted_moves_per_s": (s1.accepted_moves - s0.accepted_moves) / (kms / 1e3),
+            "kernel": "free_stage_kernel<1,false,true,false>", "launches": nl, "avg_launch_ms": kms / max(nl, 1),
+            "algorithmic_bytes_per_launch": cols * 64 * 8 / max(nl, 1), "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9}
+
+
+def bench_peak_hbm(chains, sweeps=100, d_omega=1e-5):
+    """bench.py's hbm_regime peak entry (BASELINE configs[3]: bosonic, 1000+1 deltas, 10^6+1-column table built on the device),
+    same seed and stage sequence, for the PMC passes."""
+    from sac_amd.peak import PeakProblem
+    td = synthetic_timedata(n_tau=64, seed=12345)
+    prob = PeakProblem(td, 1000, 1, 0.5, 10.0, d_omega, kernel_type="bosonic")
+    h = prob.make_handle(n_chains=chains, seed=12345, device_tables=True)
+    h.adjust_windows(200, 1.0)
+    h.sample(sweeps, 1.0)
+    s0 = h.peak_stats()
+    kms, nl = 0.0, 0
+    for _ in range(2):
+        h.sample(sweeps, 1.0)
+        s1 = h.peak_stats()
+        kms += s1.last_kernel_ms
+        nl += s1.last_kernel_launches
+    cols = s1.columns_gathered - s0.columns_gathered
+    return {"workload": f"sac/peak bosonic, N_tau=64, 1000+1 deltas, {prob.n_grid}-column table, {chains} chains, Theta=1 (bench.py hbm_regime)",
+            "chain_sweeps_per_s": (s1.sweeps - s0.sweeps) / (kms / 1e3), "launches": nl, "avg_launch_ms": kms / max(nl, 1),
+            "algorithmic_bytes_per_launch": cols * 64 * 8 / max(nl, 1), "algorithmic_GBps": cols * 64 * 8 / (kms / 1e3) / 1e9}
+
+
+def bench_free_packed(chains=8192, n_tau=22, n_omega=1000, sweeps=100):
+    """sac/free par=1 at the reference's own input shape (N_tau=22, 1000 deltas, 100001-column table), two chains per
+    wavefront (free_stage_packed_kernel), 8192 chains."""
+    from sac_amd.free import FreeProblem
+    td = synthetic_timedata(n_tau=n_tau, seed=12345)
+    prob = FreeProblem(td, n_omega, 0.0, 10.0, 1e-4, par=1, kernel_type="bosonic")
+    h = prob.make_handle(n_chains=chains, seed=12345, device_tables=True)
+    h.adjust_windows(200, 1.0)
+    h.sample(sweeps, 1.0)
+    s0 = h.stats()
+    kms, nl = 0.0, 0
+    for _ in range(2):
+        h.sample(sweeps, 1.0)
+        s1 = h.stats()
+        kms += s1.last_kernel_ms
+        nl += s1.last_kernel_launches
+    return {"workload": f"sac/free bosonic, N_tau={n_tau}, {n_omega} deltas, {prob.n_grid}-column table, {chains} chains, {h.chains_per_wave()} chains per wave",
+            "chain_sweeps_per_s": (s1.sweeps - s0.sweeps) / (kms / 1e3), "accepted_moves_per_s": (s1.accepted_moves - s0.accepted_moves) / (kms / 1e3),
+            "proposals_per_s": (s1.proposals - s0.proposals) / (kms / 1e3), "launches": nl, "avg_launch_ms": kms / max(nl, 1)}
+
+
 def bench_tables(d_omega=1e-5):
     """Row f1: the 10^6+1-column K table of BASELINE configs[3]'s regime, built on the host (numpy, as the reference's
     initialize! does) and uploaded, against built on the device (exp + fp64 MFMA basis change)."""
@@ -139,6 +205,12 @@ if __name__ == "__main__":
         print(json.dumps(bench_peak(a.chains, d_omega=a.d_omega, two_axes=True)), flush=True)
     if a.which in ("tables",):
         print(json.dumps(bench_tables(a.d_omega)), flush=True)
+    if a.which in ("free_hbm",):
+        print(json.dumps(bench_free_hbm(a.chains, d_omega=a.d_omega)), flush=True)
+    if a.which in ("peak_hbm",):
+        print(json.dumps(bench_peak_hbm(a.chains, d_omega=a.d_omega)), flush=True)
+    if a.which in ("free_packed",):
+        print(json.dumps(bench_free_packed(2 * a.chains)), flush=True)
     if a.which in ("free2",):
         print(json.dumps(bench_free2(a.chains)), flush=True)
     if a.which in ("edge", "both"):

@@ -3,6 +3,9 @@
 // per CU -- the same shape as free_stage_kernel's K-column gathers, with all arithmetic removed.
 // Also the calibration run for FETCH_SIZE on this access width (known byte count).
 //   gather_probe <table_MiB> <rows_per_wave> [waves]
+//   gather_probe --rows3 <table_MiB> <rows_per_wave> <rows_in_flight 1|2|4|8>
+//       the edge sampler's access: random 1536-B rows (K, dK, d2K of one grid column: three 512-B wave loads), a given number of
+//       rows in flight per wave and a full wait between batches -- one dependent batch per proposal, as edge_stage_kernel has it
 //   gather_probe --positions <file> <rows_per_wave>
 //       the sampler's OWN column distribution: <file> (tools/dump_positions.py) holds, for every chain of a tuned run at the
 //       bench shape, its delta positions and its tuned single-move window; wave c then gathers what chain c's single moves
@@ -35,6 +38,57 @@ __global__ void __launch_bounds__(256) gather_rows(const double *table, uint32_t
         for (int d = 0; d < DEPTH; ++d) acc += v[d];
     }
     if (acc == 123.456) out[wave] = acc;                           // keep the loads alive
+}
+
+// random 1536-B rows, INF of them in flight, then a full wait (the edge kernel's one dependent batch per proposal)
+template <int INF>
+__global__ void __launch_bounds__(64) gather_rows3(const double *table, uint32_t n_rows, int iters, double *out)
+{
+    const uint32_t wave = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t s = wave * 2654435761u + 12345u;
+    double acc = 0.0;
+    for (int it = 0; it < iters; it += INF) {
+        double v[INF][3];
+#pragma unroll
+        for (int d = 0; d < INF; ++d) {
+            s = s * 1664525u + 1013904223u;
+            s ^= (uint32_t)(acc != 123.456 ? 0u : 1u);              // next rows depend on the batch before (a chain)
+            const uint32_t row = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)s * n_rows) >> 32));
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[d][q] = table[(size_t)row * 192 + q * 64 + lane];
+        }
+#pragma unroll
+        for (int d = 0; d < INF; ++d) acc += (v[d][0] + v[d][1]) + v[d][2];
+    }
+    if (acc == 123.456) out[wave] = acc;
+}
+
+template <int INF>
+static int run_rows3(double mib, int iters, int waves)
+{
+    const uint32_t n_rows = (uint32_t)(mib * 1048576.0 / 1536.0);
+    double *table, *out;
+    if (hipMalloc(&table, (size_t)n_rows * 1536) != hipSuccess) { fprintf(stderr, "hipMalloc\n"); return 1; }
+    hipMalloc(&out, waves * sizeof(double));
+    hipMemset(table, 0, (size_t)n_rows * 1536);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int it = (iters / INF) * INF;
+    gather_rows3<INF><<<waves, 64>>>(table, n_rows, it / 10, out);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    gather_rows3<INF><<<waves, 64>>>(table, n_rows, it, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)waves * it * 1536.0;
+    printf("{\"pattern\": \"random 1536-B rows, dependent batches\", \"table_MiB\": %.1f, \"rows\": %u, \"waves\": %d, \"rows_in_flight\": %d, "
+           "\"rows_per_wave\": %d, \"bytes\": %.0f, \"ms\": %.3f, \"GBps\": %.1f, \"us_per_batch\": %.3f}\n", mib, n_rows, waves, INF, it, bytes, ms,
+           bytes / ms / 1e6, ms * 1e3 / (it / INF));
+    return 0;
 }
 
 // pairs (new, old) as chain `wave`'s single-delta proposals request them
@@ -116,6 +170,16 @@ static int run_positions(const char *path, int iters)
 
 int main(int argc, char **argv)
 {
+    if (argc > 4 && !strcmp(argv[1], "--rows3")) {
+        const double mib = atof(argv[2]);
+        const int iters = atoi(argv[3]), inf = atoi(argv[4]), waves = argc > 5 ? atoi(argv[5]) : 4096;
+        if (inf == 1) return run_rows3<1>(mib, iters, waves);
+        if (inf == 2) return run_rows3<2>(mib, iters, waves);
+        if (inf == 4) return run_rows3<4>(mib, iters, waves);
+        if (inf == 8) return run_rows3<8>(mib, iters, waves);
+        fprintf(stderr, "rows_in_flight must be 1, 2, 4 or 8\n");
+        return 1;
+    }
     if (argc > 2 && !strcmp(argv[1], "--positions")) return run_positions(argv[2], argc > 3 ? atoi(argv[3]) : 200000);
     const double mib = argc > 1 ? atof(argv[1]) : 49.0;
     const int iters = argc > 2 ? atoi(argv[2]) : 200000;
