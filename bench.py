@@ -165,6 +165,37 @@ def hbm_regime(device, chains, theta=THETA):
         run(f"sac/peak bosonic, N_tau=64, 1000+1 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
             f"{chains} chains" + (" (BASELINE.json configs[3])" if d_omega == 1e-5 else ""), f"peak_{prob.n_grid}", h, h.peak_stats, 100,
             prob.n_grid * 512, rebuild_cols=1001)
+    # BASELINE configs[2]'s kernel on one GPU: sac/edge single_edge, N_e=80, K / dK / d2K tables of 10^6+1 columns (1465 MiB),
+    # one 40-sweep launch per bin (the workload of tools/bench_param.py edge and of the PMC passes, same seeds)
+    from sac_amd.edge import EdgeProblem
+    te = synthetic_timedata(n_tau=N_TAU, seed=777)
+    prob = EdgeProblem(te, "single_edge", "bosonic", 80, 0, 0.5, 0.0, 1.0, 0.0, 10.0, 1e-5)
+    h = prob.make_handle(n_chains=chains, seed=777, device=device)
+    h.run_bins(20, 2, theta)
+    r0 = h.results(-1)
+    h.run_bins(40, 4, theta)
+    r1 = h.results(-1)
+    ms = r1["last_stage_ms"]
+    look = r1["lookups"] - r0["lookups"]
+    tab = look * 3 * N_TAU * 8 / (ms / 1e3) / 1e9
+    e = {"workload": f"sac/edge single_edge bosonic, N_tau=64, N_e=80, 3 x {prob.kernel.n_grid}-column tables (1465 MiB), {chains} chains "
+                     "(BASELINE.json configs[2] on one GPU)", "bound": "hbm (random 1536-B row gathers)", "launches": 4, "avg_launch_ms": ms / 4,
+         "peak": HBM_PEAK_GBS, "unit": "GB/s", "table_GBps": tab, "chain_sweeps_per_s": chains * 160 / (ms / 1e3),
+         "lookups_per_s": look / (ms / 1e3), "gather_ceiling_GBps": 7200.0,
+         "gather_ceiling_source": "profiles/r02_gather_probe_edge.txt (dependent random 1536-B rows of a 1465 MiB table, 4096 waves)"}
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("other", {}).get("edge")
+    except (OSError, ValueError):
+        t = None
+    if t and chains == 4096:
+        ach = t["bytes_per_launch"] / (ms / 4 / 1e3) / 1e9
+        e.update({"achieved": ach, "traffic": t["bytes_per_launch"], "frac": ach / HBM_PEAK_GBS, "frac_of_gather_ceiling": ach / 7200.0,
+                  "achieved_note": "counter traffic beyond L2 per 40-sweep launch (table rows + the chains' K_curr / K_new columns), "
+                                   "profiles/traffic.json, over the launch time of this run"})
+    else:
+        e.update({"achieved": tab, "traffic": None, "frac": tab / HBM_PEAK_GBS})
+    out.append(e)
+    h.close()
     return out
 
 
