@@ -219,6 +219,16 @@ int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_min);
 int sac_set_chains_per_wave(sac_handle_t *h, int32_t chains_per_wave);
 int sac_get_chains_per_wave(sac_handle_t *h, int32_t *last_used);
 
+/* Scheduling knob for runs with few chains (no counterpart in the reference; its annealing run IS one chain, free:1027-1262,
+ * and the latency of that chain is the run's wall-clock): how many consecutive proposals of ONE chain a wavefront evaluates
+ * per step -- 1, 2 or 4; 0 = the library chooses (2 when the handle has at most 1024 chains, i.e. at most one wave per SIMD,
+ * else 1).  The chain is the sequential one for every value, bit for bit (free_sweep_spec.h: proposals behind an accepted
+ * one are evaluated again against the new state).  par = 1 (equal fixed amplitudes) and N_tau <= 64 only; other shapes use
+ * one proposal per step.  A handle that packs several chains per wave (sac_set_chains_per_wave) does not speculate.
+ * sac_get_proposals_per_step reports what the last sweep launch used. */
+int sac_set_proposals_per_step(sac_handle_t *h, int32_t proposals_per_step);
+int sac_get_proposals_per_step(sac_handle_t *h, int32_t *last_used);
+
 /* Cross-validation scoring behind the boundary: what calc_cv.jl:29-58 computes from a GSAC.csv row
  * (cross_val.jl:105-108), taken directly from the Gbar the chains hold -- no file round trip:
  *   t = U_this Gbar (cv:106), y = U_other^T t (calc_cv.jl:37), chi2_v = sum_j ((y_j - G_other_j) sigma_inv_other_j)^2.

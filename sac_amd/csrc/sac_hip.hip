@@ -17,6 +17,7 @@
 #include "free_sweep.h"
 #include "hist_sort.h"
 #include "free_sweep_packed.h"
+#include "free_sweep_spec.h"
 #include "peak_sweep.h"
 #include "table_build.h"
 #include "cv_score.h"
@@ -711,6 +712,8 @@ struct sac_handle {
     int sweeps_per_launch = 100;
     int chains_per_wave = 0;       // sac_set_chains_per_wave: 0 = the library chooses
     int last_chains_per_wave = 1;  // what the last sweep launch used
+    int proposals_per_step = 0;    // sac_set_proposals_per_step: 0 = the library chooses
+    int last_proposals_per_step = 1;
     double *dK = nullptr, *dG = nullptr, *dSinv = nullptr, *dA = nullptr, *dGbar = nullptr;
     double *dHist = nullptr;
     uint32_t *dWi = nullptr;
@@ -1214,6 +1217,19 @@ static int packed_chains_per_wave(const sac_handle *h)
     return want;
 }
 
+// Proposals of one chain evaluated per step of the next free sweep launch (free_sweep_spec.h): the caller's choice
+// (sac_set_proposals_per_step) when the shape allows it -- equal fixed amplitudes, N_tau <= 64 and <= 4 slots x the lanes
+// of a group -- else 1 (free_stage_kernel).  Automatic: runs that leave the chip mostly empty (at most one wave per SIMD),
+// where the latency of one chain is what counts; with more chains the one-proposal kernels have the higher throughput.
+static int spec_proposals_per_step(const sac_handle *h)
+{
+    auto fits = [&](int c) { return c == 1 || (h->cfg.n_tau <= 64 && 4 * (64 / c) >= h->cfg.n_tau); };
+    int want = h->proposals_per_step;
+    if (want == 0) want = (h->cfg.n_chains <= 1024 && h->cfg.n_tau <= 64) ? 2 : 1;
+    while (want > 1 && !fits(want)) want /= 2;
+    return want;
+}
+
 // Launches `n_sweeps` sweeps in chunks; flags_first apply to the first chunk only (zeroing),
 // flags_last to the last chunk only (retune), flags_all to every chunk.
 static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_all, int flags_first,
@@ -1274,6 +1290,34 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
             }
 #undef SAC_PK
 #undef SAC_PK1
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
+            h->last_launches += 1;
+            done += chunk;
+            first = false;
+            continue;
+        }
+        const int pps = ua ? spec_proposals_per_step(h) : 1;
+        h->last_proposals_per_step = pps;
+        if (pps > 1) {
+            // few chains: one chain per wave, several of its proposals per step (free_sweep_spec.h)
+            const int lpc = 64 / pps;
+            const int T = (lpc >= h->cfg.n_tau) ? 1 : (2 * lpc >= h->cfg.n_tau) ? 2 : 4;
+            const dim3 sgrid((unsigned)h->cfg.n_chains), sblock(64);
+            const size_t lds = spec_lds_bytes(h->wi_stride);
+#define SAC_SP(C_, T_)                                                                                          \
+    do {                                                                                                        \
+        if (log) hipLaunchKernelGGL((free_stage_spec_kernel<C_, T_, true>), sgrid, sblock, lds, h->stream, p);  \
+        else hipLaunchKernelGGL((free_stage_spec_kernel<C_, T_, false>), sgrid, sblock, lds, h->stream, p);     \
+    } while (0)
+            switch (pps * 8 + T) {
+            case 2 * 8 + 1: SAC_SP(2, 1); break;
+            case 2 * 8 + 2: SAC_SP(2, 2); break;
+            case 4 * 8 + 1: SAC_SP(4, 1); break;
+            case 4 * 8 + 2: SAC_SP(4, 2); break;
+            default: SAC_SP(4, 4); break;
+            }
+#undef SAC_SP
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
             h->last_launches += 1;
@@ -1357,6 +1401,23 @@ extern "C" int sac_get_chains_per_wave(sac_handle_t *h, int32_t *last_used)
 {
     if (!h || !last_used) return fail(SAC_E_INVALID, "sac_get_chains_per_wave: null argument");
     *last_used = h->last_chains_per_wave;
+    return SAC_OK;
+}
+
+extern "C" int sac_set_proposals_per_step(sac_handle_t *h, int32_t proposals_per_step)
+{
+    if (!h) return fail(SAC_E_INVALID, "sac_set_proposals_per_step: null handle");
+    if (h->peak) return fail(SAC_E_INVALID, "sac_set_proposals_per_step: free parameterisation only");
+    if (proposals_per_step != 0 && proposals_per_step != 1 && proposals_per_step != 2 && proposals_per_step != 4)
+        return fail(SAC_E_INVALID, "sac_set_proposals_per_step: %d (0 = automatic, 1, 2 or 4)", proposals_per_step);
+    h->proposals_per_step = proposals_per_step;
+    return SAC_OK;
+}
+
+extern "C" int sac_get_proposals_per_step(sac_handle_t *h, int32_t *last_used)
+{
+    if (!h || !last_used) return fail(SAC_E_INVALID, "sac_get_proposals_per_step: null argument");
+    *last_used = h->last_proposals_per_step;
     return SAC_OK;
 }
 

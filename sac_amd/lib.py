@@ -21,7 +21,7 @@ EXPORTS = [
     "sac_edge_get_move_log",
     "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
-    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
+    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_set_proposals_per_step", "sac_get_proposals_per_step", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -152,6 +152,8 @@ def load_library():
     L.sac_upload_data.argtypes = [vp, dp, dp]
     L.sac_set_chains_per_wave.argtypes = [vp, C.c_int32]
     L.sac_get_chains_per_wave.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.sac_set_proposals_per_step.argtypes = [vp, C.c_int32]
+    L.sac_get_proposals_per_step.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sac_edge_build_tables.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_edge_upload_data.argtypes = [vp, dp, dp]
     L.sac_edge_get_tables.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -268,6 +270,17 @@ class SacHandle:
         """Chains per wavefront the last sweep launch ran with."""
         out = C.c_int32(0)
         self._check(self.L.sac_get_chains_per_wave(self.h, C.byref(out)))
+        return out.value
+
+    def set_proposals_per_step(self, proposals_per_step):
+        """0 = the library chooses; 1, 2, 4 = consecutive proposals of one chain a wavefront evaluates per step (runs with
+        few chains: same chain, shorter latency)."""
+        self._check(self.L.sac_set_proposals_per_step(self.h, int(proposals_per_step)))
+
+    def proposals_per_step(self):
+        """Proposals per step the last sweep launch ran with."""
+        out = C.c_int32(0)
+        self._check(self.L.sac_get_proposals_per_step(self.h, C.byref(out)))
         return out.value
 
     def adjust_windows(self, steps, theta):

@@ -67,6 +67,7 @@ def test_move_for_move_parity(name, kw, theta, n_adj, n_smp):
     seed, n_chains, log_chain = 20250511, 3, 1
     h = prob.make_handle(n_chains=n_chains, seed=seed, chain_offset=7, hist_copies=n_chains,
                          sweeps_per_launch=7)
+    h.set_proposals_per_step(1)          # this test is free_stage_kernel's; tests/test_gpu_free_spec.py covers 2 and 4
     per_sweep = prob.n_omega + prob.n_omega // 2 + prob.n_omega // 3
     if prob.par == 2:
         per_sweep += prob.n_omega // 2 + prob.n_omega
