@@ -237,31 +237,39 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
             int acc = 0;
             double chi2_new = 0.0;
             if (inb) {
-                double sA[NE], sAp[NE], fn[NE][NTL], fo[NE][NTL];
+                double sA[NE], sAp[NE];
 #pragma unroll
                 for (int e = 0; e < NE; ++e) { sA[e] = readlane_f64(d.A[e], j); sAp[e] = readlane_f64(d.Ap[e], j); }
+                double gnew[NTL], term = 0.0;
+                // Gbar_new and the chi2 terms are formed inside each branch: a join of the prefetched and the refetched
+                // columns would make the compiler wait for EVERY outstanding load (vmcnt(0)) at each proposal, i.e. drain
+                // the prefetch ring (as in free_sweep.h)
+                auto form = [&](const double (&fn)[NE][NTL], const double (&fo)[NE][NTL]) {
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {                   // peak:758-764, 957-967
+                        double g = c.gbar[t];
+#pragma unroll
+                        for (int pr = 0; pr < NPAIR; ++pr) {
+                            const int p = 2 * pr, n = 2 * pr + 1;
+                            g = (((g + (sAp[p] * fn[p][t])) + (sAp[n] * fn[n][t])) - (sA[p] * fo[p][t])) - (sA[n] * fo[n][t]);
+                        }
+                        gnew[t] = g;
+                        const double e_ = (g - c.G[t]) * c.sinv[t];
+                        const double e2 = e_ * e_;
+                        term = (t == 0) ? e2 : (term + e2);
+                    }
+                };
+                // (the two distinct asm comments keep the optimiser from sinking the identical arithmetic of the branches
+                // into their join, which brings the full wait back)
                 if (!was_stale) {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e)
-#pragma unroll
-                        for (int t = 0; t < NTL; ++t) { fn[e][t] = kn[u][e][t]; fo[e][t] = ko[u][e][t]; }
+                    form(kn[u], ko[u]);
+                    asm volatile("; xfer: prefetched columns" : "+v"(term));
                 } else {
+                    double fn[NE][NTL], fo[NE][NTL];
 #pragma unroll
                     for (int e = 0; e < NE; ++e) { fetch(e, s_new[e], fn[e]); fetch(e, s_old[e], fo[e]); }
-                }
-                double gnew[NTL], term = 0.0;
-#pragma unroll
-                for (int t = 0; t < NTL; ++t) {                       // peak:758-764, 957-967
-                    double g = c.gbar[t];
-#pragma unroll
-                    for (int pr = 0; pr < NPAIR; ++pr) {
-                        const int p = 2 * pr, n = 2 * pr + 1;
-                        g = (((g + (sAp[p] * fn[p][t])) + (sAp[n] * fn[n][t])) - (sA[p] * fo[p][t])) - (sA[n] * fo[n][t]);
-                    }
-                    gnew[t] = g;
-                    const double e_ = (g - c.G[t]) * c.sinv[t];
-                    const double e2 = e_ * e_;
-                    term = (t == 0) ? e2 : (term + e2);
+                    form(fn, fo);
+                    asm volatile("; xfer: refetched columns" : "+v"(term));
                 }
                 chi2_new = wave_sum_uniform(term);
                 acc = lane63_true(metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j))) ? 1 : 0;
