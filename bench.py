@@ -199,6 +199,30 @@ def hbm_regime(device, chains, theta=THETA):
     return out
 
 
+def few_chains_regime(device, theta=THETA):
+    """Latency of ONE chain when the card is almost empty (64 chains: an annealing run of the reference is one chain and its
+    Theta ladder is sequential): sweeps/s per chain with one proposal per step (free_stage_kernel) and with two
+    (free_stage_spec_kernel), at the headline shape and at the reference's own input shape."""
+    from sac_amd.free import FreeProblem
+    from sac_amd.synth import synthetic_timedata
+    out = []
+    for n_tau, n_omega in ((N_TAU, N_OMEGA), (22, 1000)):
+        td = synthetic_timedata(n_tau=n_tau, seed=SEED)
+        prob = FreeProblem(td, n_omega, 0.0, OMEGA_M, D_OMEGA, par=1, kernel_type="bosonic")
+        for pps in (1, 2):
+            h = prob.make_handle(n_chains=64, seed=SEED, device=device, device_tables=True)
+            h.set_chains_per_wave(1)
+            h.set_proposals_per_step(pps)
+            h.adjust_windows(200, theta)
+            h.sample(100, theta)
+            h.sample(200, theta)
+            ms = h.stats().last_kernel_ms
+            out.append({"workload": f"sac/free bosonic, N_tau={n_tau}, {n_omega} deltas, {prob.n_grid}-column table, 64 chains",
+                        "proposals_per_step": h.proposals_per_step(), "sweeps_per_s_per_chain": 200 / (ms / 1e3)})
+            h.close()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 
 def self_launch(args, argv):
@@ -397,6 +421,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_hbm_regime and not rehearse:
             out["hbm_regime"] = hbm_regime(local_rank, args.chains, theta)
+            out["few_chains_regime"] = few_chains_regime(local_rank, theta)
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(prob, win0, wi0, theta, procs=args.cpu_procs or None)
             out["cpu_baseline"] = cb
