@@ -9,7 +9,7 @@
 // current Gbar, all groups at once, in one instruction stream.  The chain stays the sequential one:
 //
 //   * the proposals of a step are resolved in order; the first accepted one commits (its group's Gbar_new goes to the
-//     other groups by ds_bpermute, chi2 to scalar registers, the positions to LDS), and the proposals behind it in the
+//     other groups by row / half lane swaps, chi2 to scalar registers, the positions to LDS), and the proposals behind it in the
 //     step are evaluated AGAIN against the new state -- from the columns they already hold in registers, unless the
 //     accepted move touched one of their deltas (then they are decoded again and their columns refetched, the stale
 //     rule of free_sweep.h);
