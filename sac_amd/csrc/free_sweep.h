@@ -465,25 +465,30 @@ __device__ __forceinline__ int aw_move_loop(Chain<NTL> &c, double *A, int n_it, 
                 double sA[2], sAp[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { sA[q] = readlane_f64(d.A[q], j); sAp[q] = readlane_f64(d.Ap[q], j); }
-                double fn[2][NTL], fo[2][NTL];
+                double gnew[NTL], term = 0.0;
+                // Gbar_new and the chi2 terms are formed inside each branch, and the two asm comments keep the optimiser from
+                // sinking the identical arithmetic into the join: a join of the prefetched and the refetched columns makes the
+                // compiler wait for EVERY outstanding load (vmcnt(0)) at each proposal, i.e. drain the prefetch ring
+                auto form = [&](const double (&fn)[2][NTL], const double (&fo)[2][NTL]) {
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) {                   // free:535-541
+                        const double g = (((c.gbar[t] + (sAp[0] * fn[0][t])) + (sAp[1] * fn[1][t]))
+                                          - (sA[0] * fo[0][t])) - (sA[1] * fo[1][t]);
+                        gnew[t] = g;
+                        const double e = (g - c.G[t]) * c.sinv[t];
+                        const double e2 = e * e;
+                        term = (t == 0) ? e2 : (term + e2);
+                    }
+                };
                 if (!was_stale) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int t = 0; t < NTL; ++t) { fn[q][t] = kn[u][q][t]; fo[q][t] = ko[u][q][t]; }
+                    form(kn[u], ko[u]);
+                    asm volatile("; A_w move: prefetched columns" : "+v"(term));
                 } else {
+                    double fn[2][NTL], fo[2][NTL];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { load_col<NTL>(c, s_new[q], fn[q]); load_col<NTL>(c, s_old[q], fo[q]); }
-                }
-                double gnew[NTL], term = 0.0;
-#pragma unroll
-                for (int t = 0; t < NTL; ++t) {                       // free:535-541
-                    const double g = (((c.gbar[t] + (sAp[0] * fn[0][t])) + (sAp[1] * fn[1][t]))
-                                      - (sA[0] * fo[0][t])) - (sA[1] * fo[1][t]);
-                    gnew[t] = g;
-                    const double e = (g - c.G[t]) * c.sinv[t];
-                    const double e2 = e * e;
-                    term = (t == 0) ? e2 : (term + e2);
+                    form(fn, fo);
+                    asm volatile("; A_w move: refetched columns" : "+v"(term));
                 }
                 chi2_new = wave_sum_uniform(term);
                 acc = lane63_true(metropolis(c.chi2, chi2_new, c.inv2theta, readlane_f64(d.lnu, j))) ? 1 : 0;
