@@ -520,16 +520,19 @@ struct EdgeChain {
         return lane_scatter_f64(v, (lane < n) ? r : lane);
     }
 
-    // running positions: lane q gets ((start + t_0) + t_1) ... + t_{q-1}; returns the last one (lane n-1's)
+    // running positions: lane q gets ((start + t_0) + t_1) ... + t_{q-1}; returns the last one (lane n-1's).
+    // Systolic: every step each lane takes its left neighbour's value (DPP wave_shr:1) plus that neighbour's t, so lane q is
+    // final after q steps and holds exactly the sequential sum.  Two lane shifts and one add per step on the vector ALU -- the
+    // v_readlane form cost twice the instructions and a scalar-register round trip in every step of the dependent chain.
     __device__ __forceinline__ double lane_running(double start, double t, int n, double &mine) const
     {
+        double tprev = dpp_f64<0x138>(t);                 // wave_shr:1: lane q <- t_{q-1}, lane 0 <- +0
+        tprev = (lane == 0) ? start : tprev;              // lane 0: 0 + start = start in every step
         double cur = start;
-        mine = start;
-        for (int i = 1; i < n; ++i) {
-            cur = cur + readlane_f64(t, i - 1);
-            mine = (lane == i) ? cur : mine;
-        }
-        return cur;
+        for (int i = 1; i < n; ++i) cur = dpp_f64<0x138>(cur) + tprev;
+        if (n <= 1) cur = start;
+        mine = cur;
+        return readlane_f64(cur, n - 1);
     }
 
     // multi_1 (edge:973-999), 2 <= n <= 64 positions; lane q returns the new w[2 + q] in mine
@@ -544,8 +547,8 @@ struct EdgeChain {
         const u32x4 b = block(move, iter, (uint32_t)(1 + lane / 2));          // U_u, u = lane
         const double U = (lane & 1) ? u01(b.z, b.w) : u01(b.x, b.y);
         double t = d0 + ((d1 - d0) * U);
-        double sum = 0.0;
-        for (int i = 0; i < n - 1; ++i) sum = sum + readlane_f64(t, i);
+        double part;
+        const double sum = lane_running(0.0, t, n, part);   // ((t_0 + t_1) + ...) + t_{n-2}, in index order (0 + t_0 = t_0)
         const double w1 = xa - sum;
         if (!uni(w1 > p->w_floor[rl] && w1 < ss[SS_WB0 + rl])) return 0;
         if (n > 2) t = lane_sort_asc(t, n - 1);
