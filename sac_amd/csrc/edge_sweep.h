@@ -603,7 +603,9 @@ struct EdgeChain {
             const double nj = di + dj - ni;
             t = (lane == i) ? ni : ((lane == j) ? nj : t);
         }
+        EDGE_TICK(14);
         if (n > 1) t = lane_sort_asc(t, n);
+        EDGE_TICK(15);
         const double last = lane_running(xk, t, n, mine);
         if (lane < n) mw[rl][k + lane] = mine;
         return uni(last < ss[SS_WBF + rl]) ? 1 : 0;

@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(64, EDGE_WAVES) edge_stage_kernel(const EdgePa
 #ifdef EDGE_PROF
     if (chain == 0 && lane == 0 && p.n_sweeps > 1) {
         const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(c.ss + SS_PROF);
-        printf("prof sweeps=%d: start %llu | single %llu multi %llu amp %llu measure %llu | multi: loop %llu disp %llu m1 %llu mk %llu decode %llu gather %llu chi2 %llu commit %llu\n",
-               p.n_sweeps, pr[0], pr[10], pr[11], pr[12], pr[13], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8]);
+        printf("prof sweeps=%d: start %llu | single %llu multi %llu amp %llu measure %llu | multi: loop %llu disp %llu m1 %llu mk(rest) %llu mk-pairs %llu mk-sort %llu decode %llu gather %llu chi2 %llu commit %llu\n",
+               p.n_sweeps, pr[0], pr[10], pr[11], pr[12], pr[13], pr[1], pr[2], pr[3], pr[4], pr[14], pr[15], pr[5], pr[6], pr[7], pr[8]);
     }
 #endif
     unsigned long long viol = 0;
