@@ -509,6 +509,26 @@ struct EdgeChain {
         return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
     }
 
+    // v of lane src_byte / 4 (per lane)
+    __device__ __forceinline__ double bpermute_lane_f64(int src_byte, double v) const
+    {
+        const uint64_t b = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src_byte, (int)(uint32_t)b);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src_byte, (int)(uint32_t)(b >> 32));
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+    }
+
+    // a = lane (l & 31)'s value, b = lane (l & 31) + 32's value, in every lane l (v_permlane32_swap x, x: [h0 h0], [h1 h1])
+    __device__ __forceinline__ void halves_f64(double v, double &a, double &b) const
+    {
+        const uint64_t bits = __builtin_bit_cast(uint64_t, v);
+        const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+        const auto slo = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto shi = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        a = __builtin_bit_cast(double, ((uint64_t)shi[0] << 32) | slo[0]);
+        b = __builtin_bit_cast(double, ((uint64_t)shi[1] << 32) | slo[1]);
+    }
+
     // ascending rank sort of the values of lanes 0..n-1 (ties keep lane order, as sort_asc); other lanes keep theirs
     __device__ __forceinline__ double lane_sort_asc(double v, int n) const
     {
@@ -709,6 +729,100 @@ struct EdgeChain {
         rec<LOG>((int)move, true, acc, chi2_new);
     }
 
+    // cluster_try for N_tau <= 32 (one tau slot per lane, half the wave idle in cluster_try): TWO columns per wave
+    // instruction -- lanes 0..31 work on column j, lanes 32..63 on column j + 1 of a pair.  A lane takes its column's decode
+    // (table offset, Taylor offset, amplitude) from the decoding lane by ds_bpermute instead of one v_readlane per value and
+    // column, the three table rows and the K_curr column of both columns are one load instruction each, and the increments
+    // A (K_new - K_curr) of the pair reach every lane by v_permlane32_swap, lower half's first: Gbar_new is accumulated in
+    // index order exactly as in cluster_try.  (Lanes 32..63 follow the same sums; their sigma^-1 is zero.)
+    template <bool LOG, int RL>
+    __device__ __forceinline__ void cluster_try_pairs(uint32_t move, int k, int n, double mine, double ln_u)
+    {
+        static_assert(NTL == 1, "one tau slot per lane");
+        constexpr int rl = RL;
+        constexpr int CP = 4;                          // column pairs in flight
+        const int wi = grid_index(mine);
+        const double dq = mine - ((double)wi * p->dwg);
+        long long col = (long long)wi - p->wi0;
+        col = col < 0 ? 0 : (col >= p->n_grid ? p->n_grid - 1 : col);
+        const uint32_t cb = (uint32_t)p->ntp * 8u;
+        const uint64_t boff = (uint64_t)col * (uint64_t)(3u * cb);
+        const int q0 = (lane < n) ? lane : n - 1;
+        const double Aq = A[rl][k + q0];
+        const char *tabb = reinterpret_cast<const char *>(p->tab[rl]);
+        const char *kc = reinterpret_cast<const char *>(kcurr[rl]) + (size_t)k * cb;
+        char *kw = reinterpret_cast<char *>(knew[rl]) + (size_t)k * cb;
+        const int half = lane >> 5;
+        const int tl = lane & 31;
+        const uint32_t off2 = (uint32_t)((tl < p->ntp) ? tl : p->ntp - 1) * 8u;
+        double gn[1] = {gbar[0]};
+        double raw[CP][3], old[CP], dd[CP], aa[CP];
+        EDGE_TICK(5);
+        const bool small = (n <= 2 * CP);              // one batch: the new columns stay in registers, K_new is not used
+        for (int j0 = 0; j0 < n; j0 += 2 * CP) {
+#pragma unroll
+            for (int u = 0; u < CP; ++u) {
+                const int jc = j0 + 2 * u + half;
+                const int src = ((jc < n) ? jc : n - 1) << 2;
+                const uint32_t blo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)boff);
+                const uint32_t bhi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(boff >> 32));
+                dd[u] = bpermute_lane_f64(src, dq);
+                aa[u] = bpermute_lane_f64(src, Aq);
+                const char *b = tabb + (((uint64_t)bhi << 32) | blo);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) raw[u][r] = *reinterpret_cast<const double *>(b + r * cb + off2);
+                old[u] = *reinterpret_cast<const double *>(kc + (uint32_t)(src >> 2) * cb + off2);
+            }
+#pragma unroll
+            for (int u = 0; u < CP; ++u) {
+                const int ja = j0 + 2 * u;             // the pair's first column (lower half), ja + 1 the upper half's
+                if (ja < n) {
+                    const double d = dd[u];
+                    const double kn = (raw[u][0] + (raw[u][1] * d)) + (raw[u][2] * (d * d));
+                    const double inc = aa[u] * (kn - old[u]);
+                    double inc_a, inc_b;
+                    halves_f64(inc, inc_a, inc_b);     // lower / upper half's value in every lane
+                    gn[0] = gn[0] + inc_a;
+                    if (ja + 1 < n) gn[0] = gn[0] + inc_b;
+                    raw[u][0] = kn;                    // kept for the commit of a small cluster
+                    if (!small && ja + half < n) *reinterpret_cast<double *>(kw + (uint32_t)(ja + half) * cb + off2) = kn;
+                }
+            }
+        }
+        n_cols += (uint32_t)n;
+        EDGE_TICK(6);
+        const double chi2_new = chi2_of(gn);
+        const bool acc = uni(ln_u < (chi2 - chi2_new) * inv2theta);
+        EDGE_TICK(7);
+        if (acc) {
+            gbar[0] = gn[0];
+            if (small) {
+#pragma unroll
+                for (int u = 0; u < CP; ++u) {
+                    const int jc = 2 * u + half;
+                    if (jc < n) *reinterpret_cast<double *>(const_cast<char *>(kc) + (uint32_t)jc * cb + off2) = raw[u][0];
+                }
+            } else for (int j0 = 0; j0 < n; j0 += 8) {          // K_curr columns <- K_new, four pairs in flight
+                double cp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jc = j0 + 2 * u + half;
+                    cp[u] = *reinterpret_cast<const double *>(kw + (uint32_t)((jc < n) ? jc : n - 1) * cb + off2);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int jc = j0 + 2 * u + half;
+                    if (jc < n) *reinterpret_cast<double *>(const_cast<char *>(kc) + (uint32_t)jc * cb + off2) = cp[u];
+                }
+            }
+            if (lane < n) w[rl][k + lane] = mine;
+            if (lane == 0) arc[rl][1][k] += 1.0;
+            commit_chi2(chi2_new);
+            __syncthreads();
+        }
+        rec<LOG>((int)move, true, acc, chi2_new);
+    }
+
     // edge:889-968
     template <bool LOG, int RL>
     __device__ __forceinline__ void multi_edge_move()
@@ -740,7 +854,12 @@ struct EdgeChain {
                 pass = first ? multi_1_reg<RL>(n, move, (uint32_t)i, mine) : multi_k_reg<RL>(k, n, move, (uint32_t)i, pair0, retry0, jj, mine);
                 EDGE_TICK(first ? 3 : 4);
                 if (pass != 1) { rec<LOG>((int)move, false, false, 0.0); continue; }
+                if constexpr (NTL == 1) {
+                if (p->ntp <= 32) cluster_try_pairs<LOG, RL>(move, k, n, mine, readlane_f64(lnu, jj));
+                else cluster_try<LOG, RL>(move, k, n, mine, readlane_f64(lnu, jj));
+            } else {
                 cluster_try<LOG, RL>(move, k, n, mine, readlane_f64(lnu, jj));
+            }
                 EDGE_TICK(8);
                 continue;
             }
