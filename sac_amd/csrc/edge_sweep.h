@@ -594,19 +594,23 @@ struct EdgeChain {
         uint32_t retry = 0;
         const int npair = n / 2;
         // pair 0's block and the first retry block of this iteration were drawn by lane jj of the caller's group
-        // (pair0, retry0); clusters of 4 and more draw pairs 1.. here, pair q on lane q
-        u32x4 pb0 = pair0;
+        // (pair0, retry0); clusters of 4 and more draw pairs 1.. here, pair q on lane q.  The pair's two indices and its
+        // uniform are decoded by the drawing lane (lane-parallel, off the sequential path) and read from there.
+        int ip = index_from_word(pair0.x, (uint32_t)n), jp = index_from_word(pair0.y, (uint32_t)n);
+        double Up = u01(pair0.z, pair0.w);
         int src = jj;
         for (int q = 0; q < npair; ++q) {
-            if (q == 1) { pb0 = block(move, iter, (uint32_t)(1 + lane)); src = 1; }
-            const uint32_t wx = (uint32_t)__builtin_amdgcn_readlane((int)pb0.x, src);
-            const uint32_t wy = (uint32_t)__builtin_amdgcn_readlane((int)pb0.y, src);
-            const uint32_t wz = (uint32_t)__builtin_amdgcn_readlane((int)pb0.z, src);
-            const uint32_t ww = (uint32_t)__builtin_amdgcn_readlane((int)pb0.w, src);
-            const double U = u01(wz, ww);
+            if (q == 1) {
+                const u32x4 pb = block(move, iter, (uint32_t)(1 + lane));
+                ip = index_from_word(pb.x, (uint32_t)n);
+                jp = index_from_word(pb.y, (uint32_t)n);
+                Up = u01(pb.z, pb.w);
+                src = 1;
+            }
+            const int i = __builtin_amdgcn_readlane(ip, src);
+            int j = __builtin_amdgcn_readlane(jp, src);
+            const double U = readlane_f64(Up, src);
             if (q >= 1) src += 1;
-            const int i = index_from_word(wx, (uint32_t)n);
-            int j = index_from_word(wy, (uint32_t)n);
             while (j == i) {
                 if (retry > 255) return 0;
                 uint32_t rx;
