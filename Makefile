@@ -7,7 +7,7 @@ HDR = $(wildcard sac_amd/csrc/*.h) include/sac_hip.h
 all: sac_amd/libsac_hip.so oracle
 
 sac_amd/libsac_hip.so: $(SRC) $(HDR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRC) -ldl
 
 asm: $(SRC) $(HDR)
 	mkdir -p build && $(HIPCC) $(HIPFLAGS) -S --cuda-device-only -o build/sac_hip.s sac_amd/csrc/sac_hip.hip -Rpass-analysis=kernel-resource-usage 2> build/resource_usage.txt

@@ -87,6 +87,9 @@ typedef struct {
     double   last_stage_ms;    /* device time of the last adjust_windows / sample call */
     double   last_kernel_ms;   /* device time spent in the sweep kernel proper during it */
     int64_t  last_kernel_launches;
+    double   chi2_min_mean;    /* mean over chains of each chain's OWN chi2_min: what ONE chain of the reference sees
+                                  (free:315-317); the drivers' single-chain-equivalent for the Theta criteria (free:1087, 1249) */
+    int64_t  n_chains_total;   /* chains behind these numbers: n_chains, or the sum over ranks after sac_comm_init */
 } sac_stats_t;
 
 typedef struct {               /* SAC_KIND_PEAK: what sac_peak.jl's CSV writers print (peak:1301-1333, 1386-1421) */
@@ -102,6 +105,8 @@ typedef struct {               /* SAC_KIND_PEAK: what sac_peak.jl's CSV writers 
     uint64_t proposals, evaluated, accepted, accepted_moves, sweeps, columns_gathered;
     double   last_stage_ms, last_kernel_ms;
     int64_t  last_kernel_launches;
+    double   chi2_min_mean;    /* mean over chains of each chain's own chi2_min (peak:1343, 1545 see ONE chain's) */
+    int64_t  n_chains_total;   /* n_chains, or the sum over ranks after sac_comm_init */
 } sac_peak_stats_t;
 
 typedef struct {
@@ -133,6 +138,9 @@ int sac_get_state(sac_handle_t *h, int32_t chain, int64_t *wi, double *A, double
 int sac_init_gbar(sac_handle_t *h);
 int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min);
 int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, double chi2, double chi2_min);
+/* Gbar averaged over the handle's chains, n_tau doubles (the row cross_val.jl:105-108 dumps is cov * Gbar of ONE chain);
+ * after a merged sample stage (sac_comm_init) the average over all ranks' chains. */
+int sac_get_gbar_mean(sac_handle_t *h, double *gbar_mean);
 
 /* adjust_windows(self, steps, theta)  free:866-899 */
 int sac_adjust_windows(sac_handle_t *h, int64_t steps, double theta);
@@ -268,6 +276,29 @@ typedef struct {
 int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, const sac_peak_proposal_t *props, int64_t n,
                     double *chi2_new, int32_t *accepted);
 
+/* ---- multi-GPU merge behind the boundary (SURVEY section 8e, 8b-5 "already reduced over chains and GPUs") -------------
+ * No counterpart in the reference, whose only fan-out is one Julia process per parameter point / replica with files as
+ * the hand-off (sac/cross_validation/run_cv.sh:5-9, sac/qsub_files/edge/submit.sh:25-51).  One process per GPU holds a
+ * block of the chains of one problem (sac_config_t.chain_offset = the global id of its first chain).  Once a
+ * communicator is attached, EVERY stage entry point (sac_init_gbar, sac_adjust_windows, sac_sample, sac_sample_bin;
+ * sac_edge_init_gbar, sac_edge_run_bins) ends with the merge of the ranks' partial sums -- exactly ONE
+ * ncclAllReduce(sum) over the fused device buffer [histogram(s) | per-delta averages | scalar sums | chain count] and
+ * ONE ncclAllReduce(min) for chi2_min, in place on device memory on the handle's stream -- and the reduced getters
+ * (sac_get_stats, sac_get_peak_stats, sac_get_histogram, sac_get_histogram_peak; sac_edge_get_results / _accept_rates /
+ * _histogram / _avg with chain = -1) return the values over ALL ranks, identical on every rank, so every rank takes the
+ * same Theta-schedule decisions (free:1087, 1128, 1249-1252; peak:1343, 1545; edge:1680-1688, 1718).  The stage calls
+ * are collective: every rank makes the same sequence of them.  Per-chain getters stay local.  Writing state from the
+ * host (sac_set_state, sac_set_gbar, sac_copy_chain, ...) drops the merged view until the next stage call; the reduced
+ * getters then answer for the local chains (n_chains_total tells which).
+ * RCCL (librccl.so.1; SAC_RCCL_LIB overrides the name) is loaded when the first of these is called. */
+#define SAC_COMM_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to the other ranks (file, socket, MPI, torch broadcast) */
+int sac_comm_unique_id(void *id128);
+/* ncclCommInitRank on the handle's GPU (collective over all ranks) + the merge buffers; released by sac_destroy */
+int sac_comm_init(sac_handle_t *h, const void *id128, int32_t rank, int32_t world);
+/* rank, world, stages merged and all-reduce calls issued so far (2 per merged stage); any pointer may be NULL */
+int sac_comm_info(sac_handle_t *h, int32_t *rank, int32_t *world, int64_t *merges, int64_t *allreduce_calls);
+
 /* Debug/parity: record every proposal of one chain (up to capacity) during the following stages. */
 int sac_set_move_log(sac_handle_t *h, int32_t chain, int64_t capacity);
 int sac_get_move_log(sac_handle_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
@@ -308,6 +339,10 @@ typedef struct {
     double   chi2, chi2_min;
     uint64_t sweeps, proposals, evaluated, accepted, lookups, violations;
     double   last_stage_ms;
+    double   chi2_min_mean;         /* chain = -1: mean over chains of each chain's own chi2_min (edge:1682, 1718 see ONE
+                                       chain's); one chain: its chi2_min */
+    int64_t  n_chains_total;        /* chains behind a chain = -1 result: n_chains, or the sum over ranks after
+                                       sac_edge_comm_init */
 } sac_edge_results_t;
 
 int sac_edge_create(const sac_edge_config_t *cfg, sac_edge_t **out);
@@ -343,6 +378,12 @@ int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side, double *o
 /* omega_avg, A_avg (edge:83-84, 1314-1315): [N_w+1, 2] accumulated sums */
 int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, double *A_avg);
 int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min);
+/* What write_res prints about the moves (edge:1454-1460, 1484-1506), averaged over the handle's chains (all ranks' after a
+ * merged stage): D_omega_array and n_multi as [N_w+1, 2] means, cont_extent = {lowest, highest continuum frequency of
+ * side 1} (0, 0 without continuum).  Any pointer may be NULL. */
+int sac_edge_get_move_means(sac_edge_t *h, double *dw_mean, double *n_multi_mean, double *cont_extent);
+/* Gbar averaged over the handle's chains (cv:494-497), or over all ranks' chains after a merged stage */
+int sac_edge_get_gbar_mean(sac_edge_t *h, double *gbar_mean);
 /* Parity / debug entry (no counterpart in the reference): an explicit stream of position proposals on one
  * chain -- new frequencies w_new[w_offset .. w_offset+n-1] for the n consecutive deltas k .. k+n-1 (Julia's 1-based index,
  * 2 .. N_w+1) of one side, and the accept draw.  n = 1: what single_edge_move / single_cont_move evaluate once index, shift
@@ -361,6 +402,9 @@ int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const sac_edge_p
 /* sac_validation_chi2 for an edge handle (cv:494-497 + calc_cv.jl:29-58) */
 int sac_edge_validation_chi2(sac_edge_t *h, const double *U_this, const double *U_other, const double *G_other,
                              const double *sigma_inv_other, const double *gbar_mean, double *chi2_mean, double *chi2_chain);
+/* the multi-GPU merge for an edge handle: see sac_comm_init */
+int sac_edge_comm_init(sac_edge_t *h, const void *id128, int32_t rank, int32_t world);
+int sac_edge_comm_info(sac_edge_t *h, int32_t *rank, int32_t *world, int64_t *merges, int64_t *allreduce_calls);
 int sac_edge_set_move_log(sac_edge_t *h, int32_t chain, int64_t capacity);
 int sac_edge_get_move_log(sac_edge_t *h, sac_move_rec_t *out, int64_t capacity, int64_t *n_recorded);
 

@@ -118,24 +118,21 @@ def peak_cv(rep, ab, in_file="in_peak.in", A_0=None, N_p=None, validate_tin=None
     s.initialize()
     s.write_log("Initialization Finished.")
     s.intial_sampling(s.theta_0)
-    if s.chi2_min > 1000 * s.td.n_tau:
+    if s.chi2_min_all > 1000 * s.td.n_tau:
         s.indiv_update = True
         s.initialize()
         s.intial_sampling(s.theta_0)
     s.repair_chains()
 
     def dump(i, theta):
-        g = np.zeros(s.td.n_tau)
-        for c in range(s.n_chains):
-            g += s.h.get_gbar(c)[0][: s.td.n_tau]
-        n = float(s.n_chains)
-        if s.comm is not None:                                      # chain mean over all ranks, as edge_cv does
-            tot = s.comm.sum_vector(np.concatenate([g, [n]]))
-            g, n = tot[:-1], tot[-1]
+        g = s.h.gbar_mean()                                         # one call; over all ranks when the handle merges
+        if s.comm is not None and not s.h.merged_over_ranks:        # host-side groups
+            tot = s.comm.sum_vector(np.concatenate([g * s.n_chains, [float(s.n_chains)]]))
+            g = tot[:-1] / tot[-1]
         if s.is_root:
-            _append_gsac(gsac, theta, s.td.cov, g / n)
+            _append_gsac(gsac, theta, s.td.cov, g)
         if score is not None:
-            score(theta, gbar_mean=(g / n) if s.comm is not None else None)
+            score(theta, gbar_mean=g if s.comm is not None else None)
 
     score = _fused_validation(s, validate_tin)
     s.run_anneal(s.theta_0, on_stage=dump)
@@ -174,11 +171,8 @@ def edge_cv(rep, ab, in_file="in_edge.in", A_c=None, A_r=None, p=None, validate_
             steps = int(math.ceil(s.anneal_steps / 6))
         s.run_bins(steps, s.bins, theta)
         s.write_res(i, theta)
-        g = np.zeros(s.td.n_tau)
-        for c in range(s.n_chains):
-            g += s.h.get_gbar(c)[0]
-        g /= s.n_chains
-        if s.comm is not None:
+        g = s.h.gbar_mean()                                         # one call; over all ranks when the handle merges
+        if s.comm is not None and not s.h.merged_over_ranks:        # host-side groups
             tot = s.comm.sum_vector(np.concatenate([g * s.n_chains, [float(s.n_chains)]]))
             g = tot[:-1] / tot[-1]
         if s.is_root:

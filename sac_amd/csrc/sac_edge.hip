@@ -14,6 +14,7 @@
 #include "edge_sweep.h"
 #include "table_build.h"
 #include "cv_score.h"
+#include "comm.h"
 
 using namespace sacdev;
 
@@ -420,6 +421,105 @@ __global__ void __launch_bounds__(64) edge_init_kernel(const EdgeParams p)
     }
 }
 
+// ---- per-stage merge over ranks (comm.h) --------------------------------------------------------------------------
+// dst[i] = sum over `rows` rows of src[r * row_len + i], rows in index order (the histogram replicas)
+__global__ void edge_sum_rows_kernel(const double *src, int rows, long long row_len, double *dst)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_len) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s = s + src[(size_t)r * (size_t)row_len + (size_t)i];
+    dst[i] = s;
+}
+
+// dst[g * n1 + k - 1] = sum over chains of src[c * chain_stride + g * S + k], k = 1 .. n1 (per-delta arrays keep Julia's index)
+__global__ void edge_sum_chains_kernel(const double *src, int n_chains, long long chain_stride, int groups, int S, int n1, double *dst)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= groups * n1) return;
+    const int g = i / n1, k = i % n1 + 1;
+    double s = 0.0;
+    for (int c = 0; c < n_chains; ++c) s = s + src[(size_t)c * (size_t)chain_stride + (size_t)g * S + k];
+    dst[i] = s;
+}
+
+// dst[t] = sum over chains of Gbar[c][t], chains in index order
+__global__ void edge_gbar_sum_kernel(const double *gbar, int n_chains, double *dst)
+{
+    const int t = (int)threadIdx.x;
+    if (t >= SAC_MAX_N_TAU) return;
+    double s = 0.0;
+    for (int c = 0; c < n_chains; ++c) s = s + gbar[(size_t)c * SAC_MAX_N_TAU + t];
+    dst[t] = s;
+}
+
+// dst[g * n1 + k - 1] = sum over chains of (double) src[c * chain_stride + g * S + k]: the cluster sizes n_multi (edge:73)
+__global__ void edge_sum_chains_int_kernel(const int *src, int n_chains, long long chain_stride, int groups, int S, int n1, double *dst)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= groups * n1) return;
+    const int g = i / n1, k = i % n1 + 1;
+    double s = 0.0;
+    for (int c = 0; c < n_chains; ++c) s = s + (double)src[(size_t)c * (size_t)chain_stride + (size_t)g * S + k];
+    dst[i] = s;
+}
+
+// dst[0], dst[1] = sum over chains of the lowest / highest continuum frequency of side 0 (what write_res prints, edge:1454-1460)
+__global__ void edge_cont_extent_kernel(const double *w, int n_chains, int S, int NE, int N, double *dst)
+{
+    const int t = (int)threadIdx.x;
+    if (t >= 2) return;
+    double s = 0.0;
+    for (int c = 0; c < n_chains; ++c) {
+        const double *x = w + (size_t)c * 2 * (size_t)S;
+        double m = x[NE + 2];
+        for (int k = NE + 3; k <= N + 1; ++k) m = (t == 0) ? (x[k] < m ? x[k] : m) : (x[k] > m ? x[k] : m);
+        s = s + m;
+    }
+    dst[t] = s;
+}
+
+constexpr int EDGE_SLOTS = 46;  // chi2_res[3], edge_res[6], n0_res[6], wn0_res[6], amp_ar[6], n0[2], eps0[2], dn0[2], deps0[2], chi2,
+                                // sum chi2_min, proposals, evaluated, accepted, lookups, violations, chains, sums of the lowest
+                                // and of the highest continuum frequency (43, 44), spare
+
+// one thread per slot: bin_averages (edge:1436-1449) of every chain, summed over the chains in index order
+__global__ void edge_pack_kernel(const EdgeScalars *sc, int n_chains, double bins, int n_rl, double *out_sum, double *out_min)
+{
+    const int t = (int)threadIdx.x;
+    if (t >= EDGE_SLOTS) return;
+    const double den = sqrt(bins - 1.0);
+    double s = 0.0, mn = sc[0].chi2_min;
+    for (int c = 0; c < n_chains; ++c) {
+        const EdgeScalars &x = sc[c];
+        double v = 0.0;
+        if (t < 3) {
+            v = x.chi2_res[t] / bins;
+            if (t == 2) { const double m = x.chi2_res[1] / bins; v = sqrt(fabs(v - m * m)) / den; }
+        } else if (t < 21) {
+            const int a = (t - 3) / 6, q = ((t - 3) % 6) / 2, rl = (t - 3) % 2;
+            const double (*res)[2] = a == 0 ? x.edge_res : a == 1 ? x.n0_res : x.wn0_res;
+            v = res[q][rl] / bins;
+            if (q == 2 && rl < n_rl) { const double m = res[1][rl] / bins; v = sqrt(fabs(v - m * m)) / den; }
+        } else if (t < 27) v = x.amp_ar[(t - 21) / 2][(t - 21) % 2];
+        else if (t < 29) v = x.n0[t - 27];
+        else if (t < 31) v = x.eps0[t - 29];
+        else if (t < 33) v = x.dn0[t - 31];
+        else if (t < 35) v = x.deps0[t - 33];
+        else if (t == 35) v = x.chi2;
+        else if (t == 36) { v = x.chi2_min; if (x.chi2_min < mn) mn = x.chi2_min; }
+        else if (t == 37) v = (double)x.counters[0];
+        else if (t == 38) v = (double)x.counters[1];
+        else if (t == 39) v = (double)x.counters[2];
+        else if (t == 40) v = (double)x.counters[4];
+        else if (t == 41) v = (double)x.violations;
+        else if (t == 42) v = 1.0;
+        s = s + v;
+    }
+    out_sum[t] = s;
+    if (t == 36) out_min[0] = mn;
+}
+
 // =========================================================================================
 // Host side
 // =========================================================================================
@@ -446,6 +546,18 @@ struct sac_edge {
     int64_t last_steps = 0, last_bins = 0;
     double last_stage_ms = 0.0;
     double ms_per_sweep = 0.0;     // measured stage time per sweep (priority rotation period)
+    saccomm::Comm *comm = nullptr; // sac_edge_comm_init: per-stage merge over ranks
+    double *dGbarSum = nullptr;    // [128] sac_edge_get_gbar_mean without a communicator
+    double *dMeans = nullptr;      // [4 n1 + 2] sac_edge_get_move_means without a communicator
+    // layout of the fused merge buffer: [hist 4 n_grid | w_avg 2 n1 | A_avg 2 n1 | accept rates 4 n1 | sum of Gbar 128 |
+    //                                    windows 2 n1 | cluster sizes 2 n1 | EDGE_SLOTS]
+    size_t off_wavg() const { return 4 * (size_t)cfg.n_grid; }
+    size_t off_aavg() const { return off_wavg() + 2 * (size_t)(cfg.n_omega + 1); }
+    size_t off_arc() const { return off_aavg() + 2 * (size_t)(cfg.n_omega + 1); }
+    size_t off_gbar() const { return off_arc() + 4 * (size_t)(cfg.n_omega + 1); }
+    size_t off_dw() const { return off_gbar() + SAC_MAX_N_TAU; }
+    size_t off_nm() const { return off_dw() + 2 * (size_t)(cfg.n_omega + 1); }
+    size_t n_payload() const { return off_nm() + 2 * (size_t)(cfg.n_omega + 1); }
 };
 
 static int use_device(sac_edge *h)
@@ -533,6 +645,8 @@ extern "C" int sac_edge_create(const sac_edge_config_t *cfg, sac_edge_t **out)
     EALLOC(h->dHist, (size_t)h->hist_copies * 4 * (size_t)cfg->n_grid * sizeof(double));
     EALLOC(h->dSc, nc * sizeof(EdgeScalars));
     EALLOC(h->dLogLen, sizeof(unsigned long long));
+    EALLOC(h->dGbarSum, SAC_MAX_N_TAU * sizeof(double));
+    EALLOC(h->dMeans, (4 * ((size_t)cfg->n_omega + 1) + 2) * sizeof(double));
 #undef EALLOC
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) {
@@ -549,9 +663,11 @@ extern "C" int sac_edge_destroy(sac_edge_t *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->dTab[0], h->dTab[1], h->dG, h->dSinv, h->dW, h->dA, h->dDw, h->dMw, h->dNm, h->dArc, h->dKcurr,
-                    h->dKnew, h->dGbar, h->dWavg, h->dAavg, h->dHist, h->dSc, h->dLog, h->dLogLen};
+                    h->dKnew, h->dGbar, h->dWavg, h->dAavg, h->dHist, h->dSc, h->dLog, h->dLogLen, h->dGbarSum, h->dMeans};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    saccomm::destroy(h->comm);
+    h->comm = nullptr;
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -693,6 +809,7 @@ extern "C" int sac_edge_set_state(sac_edge_t *h, int32_t chain, const double *w,
             if (!std::isfinite(w[i])) return efail(SAC_E_INVALID, "sac_edge_set_state: non-finite frequency");
     int rc;
     if ((rc = use_device(h))) return rc;
+    if (h->comm) h->comm->merged = false;
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
     auto put_d = [&](double *dst, const double *src) -> int {
@@ -770,6 +887,7 @@ extern "C" int sac_edge_init_gbar(sac_edge_t *h)
     if (!h->problem || !h->state_set) return efail(SAC_E_STATE, "sac_edge_init_gbar: upload the problem and set the state first");
     int rc;
     if ((rc = use_device(h))) return rc;
+    if (h->comm) h->comm->merged = false;
     EdgeParams p;
     fill_params(h, p);
     const dim3 grid((unsigned)h->cfg.n_chains), block(64);
@@ -805,6 +923,40 @@ static int launch_stage(sac_edge *h, EdgeParams &p)
     return SAC_OK;
 }
 
+// The per-stage merge over ranks (include/sac_hip.h "multi-GPU merge"): histogram replicas, per-delta averages and accept
+// rates summed over this rank's chains into the payload, the bin averages packed behind them, ONE all-reduce(sum) + ONE
+// all-reduce(min), merged scalars read back.
+static int edge_comm_merge(sac_edge *h)
+{
+    if (!h->comm) return SAC_OK;
+    saccomm::Comm *c = h->comm;
+    const int nc = h->cfg.n_chains, n1 = h->cfg.n_omega + 1, S = h->S;
+    const long long nh = 4ll * (long long)h->cfg.n_grid;
+    hipLaunchKernelGGL(edge_sum_rows_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double *)h->dHist, h->hist_copies, nh, c->dSum);
+    hipLaunchKernelGGL(edge_sum_chains_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double *)h->dWavg, nc, 2ll * S, 2, S, n1, c->dSum + h->off_wavg());
+    hipLaunchKernelGGL(edge_sum_chains_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double *)h->dAavg, nc, 2ll * S, 2, S, n1, c->dSum + h->off_aavg());
+    hipLaunchKernelGGL(edge_sum_chains_kernel, dim3((unsigned)((4 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double *)h->dArc, nc, 4ll * S, 4, S, n1, c->dSum + h->off_arc());
+    hipLaunchKernelGGL(edge_gbar_sum_kernel, dim3(1), dim3(SAC_MAX_N_TAU), 0, h->stream, (const double *)h->dGbar, nc,
+                       c->dSum + h->off_gbar());
+    hipLaunchKernelGGL(edge_sum_chains_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const double *)h->dDw, nc, 2ll * S, 2, S, n1, c->dSum + h->off_dw());
+    hipLaunchKernelGGL(edge_sum_chains_int_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                       (const int *)h->dNm, nc, 2ll * S, 2, S, n1, c->dSum + h->off_nm());
+    hipLaunchKernelGGL(edge_pack_kernel, dim3(1), dim3(64), 0, h->stream, (const EdgeScalars *)h->dSc, nc, (double)h->last_bins,
+                       h->cfg.n_rl, c->dSum + h->n_payload(), c->dMin);
+    if (h->cfg.n_omega > h->cfg.n_e)      // after the pack kernel in stream order: it writes 0 into slots 43, 44
+        hipLaunchKernelGGL(edge_cont_extent_kernel, dim3(1), dim3(64), 0, h->stream, (const double *)h->dW, nc, S, h->cfg.n_e,
+                           h->cfg.n_omega, c->dSum + h->n_payload() + 43);
+    HIP_TRY(hipGetLastError());
+    char msg[256];
+    if (saccomm::merge(c, h->n_payload(), true, h->stream, msg, sizeof(msg))) return efail(SAC_E_HIP, "merge over ranks: %s", msg);
+    return SAC_OK;
+}
+
 // run_bins(self, steps, bins, theta)  edge:1357-1379 (bin_averages is applied by sac_edge_get_results)
 extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, double theta)
 {
@@ -815,6 +967,7 @@ extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, dou
     if (!(theta > 0) || !std::isfinite(theta)) return efail(SAC_E_INVALID, "sac_edge_run_bins: theta=%g", theta);
     int rc;
     if ((rc = use_device(h))) return rc;
+    if (h->comm) h->comm->merged = false;
     const size_t nc = (size_t)h->cfg.n_chains, S = (size_t)h->S;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     // edge:1359-1365: zero the results, spectra and averages
@@ -857,7 +1010,7 @@ extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, dou
     if (steps * bins > 0 && ms > 0.f) h->ms_per_sweep = (double)ms / (double)(steps * bins);
     h->last_steps = steps;
     h->last_bins = bins;
-    return SAC_OK;
+    return edge_comm_merge(h);
 }
 
 // bin_averages (edge:1436-1449) of one chain's accumulators
@@ -890,6 +1043,35 @@ extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_resul
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chain < 0 && h->comm && h->comm->merged) {                   // the values over all ranks (edge_comm_merge)
+        const double *t = h->comm->hTail;
+        const double n = t[42];
+        std::memset(out, 0, sizeof(*out));
+        for (int q = 0; q < 3; ++q) {
+            out->chi2_res[q] = t[q] / n;
+            for (int rl = 0; rl < 2; ++rl) {
+                out->edge_res[q][rl] = t[3 + q * 2 + rl] / n;
+                out->n0_res[q][rl] = t[9 + q * 2 + rl] / n;
+                out->wn0_res[q][rl] = t[15 + q * 2 + rl] / n;
+                out->amp_accept_rates[q][rl] = t[21 + q * 2 + rl] / n;
+            }
+        }
+        for (int rl = 0; rl < 2; ++rl) {
+            out->n0[rl] = t[27 + rl] / n; out->eps0[rl] = t[29 + rl] / n;
+            out->dn0[rl] = t[31 + rl] / n; out->deps0[rl] = t[33 + rl] / n;
+        }
+        out->chi2 = t[35] / n;
+        out->chi2_min_mean = t[36] / n;
+        out->chi2_min = t[EDGE_SLOTS];
+        out->proposals = (uint64_t)t[37]; out->evaluated = (uint64_t)t[38]; out->accepted = (uint64_t)t[39];
+        out->lookups = (uint64_t)t[40]; out->violations = (uint64_t)t[41];
+        out->n_chains_total = (int64_t)n;
+        EdgeScalars last;
+        HIP_TRY(hipMemcpy(&last, h->dSc + (nc - 1), sizeof(last), hipMemcpyDeviceToHost));
+        out->sweeps = last.sweep;
+        out->last_stage_ms = h->last_stage_ms;
+        return SAC_OK;
+    }
     const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
     std::vector<EdgeScalars> sc((size_t)count);
     HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
@@ -913,11 +1095,13 @@ extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_resul
             out->dn0[rl] += s.dn0[rl] / count; out->deps0[rl] += s.deps0[rl] / count;
         }
         out->chi2 += s.chi2 / count;
+        out->chi2_min_mean += s.chi2_min / count;
         if (s.chi2_min < out->chi2_min) out->chi2_min = s.chi2_min;
         out->sweeps = s.sweep;
         out->proposals += s.counters[0]; out->evaluated += s.counters[1]; out->accepted += s.counters[2];
         out->lookups += s.counters[4]; out->violations += s.violations;
     }
+    out->n_chains_total = count;
     out->last_stage_ms = h->last_stage_ms;
     return SAC_OK;
 }
@@ -932,6 +1116,13 @@ extern "C" int sac_edge_get_accept_rates(sac_edge_t *h, int32_t chain, int32_t m
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chain < 0 && h->comm && h->comm->merged) {                   // mean over all ranks' chains (edge_comm_merge)
+        HIP_TRY(hipMemcpy(out, h->comm->dSum + h->off_arc() + ((size_t)side * 2 + (size_t)m) * (size_t)n1, (size_t)n1 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+        const double n = h->comm->hTail[42];
+        for (int k = 0; k < n1; ++k) out[k] = out[k] / n;
+        return SAC_OK;
+    }
     const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
     std::vector<double> buf((size_t)count * 4 * S);
     HIP_TRY(hipMemcpy(buf.data(), h->dArc + (size_t)first * 4 * S, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -950,6 +1141,13 @@ extern "C" int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ng = (size_t)h->cfg.n_grid;
+    if (h->comm && h->comm->merged) {                                // mean over all ranks' chains (edge_comm_merge)
+        HIP_TRY(hipMemcpy(out, h->comm->dSum + ((size_t)side * 2 + (size_t)which) * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
+        const double n = h->comm->hTail[42];
+        if (n > 1)
+            for (size_t i = 0; i < ng; ++i) out[i] = out[i] / n;
+        return SAC_OK;
+    }
     std::vector<double> tmp(ng);
     for (size_t i = 0; i < ng; ++i) out[i] = 0.0;
     for (int c = 0; c < h->hist_copies; ++c) {
@@ -972,6 +1170,17 @@ extern "C" int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, dou
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (chain < 0 && h->comm && h->comm->merged) {                   // mean over all ranks' chains (edge_comm_merge)
+        const double n = h->comm->hTail[42];
+        for (int pass = 0; pass < 2; ++pass) {
+            double *dst = pass == 0 ? w_avg : A_avg;
+            if (!dst) continue;
+            HIP_TRY(hipMemcpy(dst, h->comm->dSum + (pass == 0 ? h->off_wavg() : h->off_aavg()), (size_t)(2 * n1) * sizeof(double),
+                              hipMemcpyDeviceToHost));
+            for (int i = 0; i < 2 * n1; ++i) dst[i] = dst[i] / n;
+        }
+        return SAC_OK;
+    }
     const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
     std::vector<double> buf((size_t)count * 2 * S);
     for (int pass = 0; pass < 2; ++pass) {
@@ -1163,6 +1372,85 @@ extern "C" int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, dou
     HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
     if (chi2) *chi2 = s.chi2;
     if (chi2_min) *chi2_min = s.chi2_min;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_comm_init(sac_edge_t *h, const void *id128, int32_t rank, int32_t world)
+{
+    if (!h || !id128) return efail(SAC_E_INVALID, "sac_edge_comm_init: null argument");
+    if (h->comm) return efail(SAC_E_STATE, "sac_edge_comm_init: the handle has a communicator already");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    char msg[320];
+    h->comm = saccomm::create(id128, rank, world, h->n_payload(), EDGE_SLOTS, 1, msg, sizeof(msg));
+    if (!h->comm) return efail(SAC_E_HIP, "sac_edge_comm_init: %s", msg);
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_comm_info(sac_edge_t *h, int32_t *rank, int32_t *world, int64_t *merges, int64_t *allreduce_calls)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_comm_info: null handle");
+    if (rank) *rank = h->comm ? h->comm->rank : 0;
+    if (world) *world = h->comm ? h->comm->world : 1;
+    if (merges) *merges = h->comm ? h->comm->merges : 0;
+    if (allreduce_calls) *allreduce_calls = h->comm ? h->comm->allreduce_calls : 0;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_move_means(sac_edge_t *h, double *dw_mean, double *n_multi_mean, double *cont_extent)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_get_move_means: null handle");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const int nc = h->cfg.n_chains, n1 = h->cfg.n_omega + 1, S = h->S;
+    const bool cont = h->cfg.n_omega > h->cfg.n_e;
+    std::vector<double> buf(4 * (size_t)n1 + 2, 0.0);
+    double n = (double)nc;
+    if (h->comm && h->comm->merged) {                                // summed over all ranks' chains (edge_comm_merge)
+        HIP_TRY(hipMemcpy(buf.data(), h->comm->dSum + h->off_dw(), 4 * (size_t)n1 * sizeof(double), hipMemcpyDeviceToHost));
+        buf[4 * (size_t)n1] = h->comm->hTail[43];
+        buf[4 * (size_t)n1 + 1] = h->comm->hTail[44];
+        n = h->comm->hTail[42];
+    } else {
+        hipLaunchKernelGGL(edge_sum_chains_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double *)h->dDw, nc, 2ll * S, 2, S, n1, h->dMeans);
+        hipLaunchKernelGGL(edge_sum_chains_int_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
+                           (const int *)h->dNm, nc, 2ll * S, 2, S, n1, h->dMeans + 2 * n1);
+        HIP_TRY(hipMemsetAsync(h->dMeans + 4 * n1, 0, 2 * sizeof(double), h->stream));
+        if (cont)
+            hipLaunchKernelGGL(edge_cont_extent_kernel, dim3(1), dim3(64), 0, h->stream, (const double *)h->dW, nc, S, h->cfg.n_e,
+                               h->cfg.n_omega, h->dMeans + 4 * n1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(buf.data(), h->dMeans, buf.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    for (int i = 0; i < 2 * n1; ++i) {
+        if (dw_mean) dw_mean[i] = buf[(size_t)i] / n;
+        if (n_multi_mean) n_multi_mean[i] = buf[2 * (size_t)n1 + (size_t)i] / n;
+    }
+    if (cont_extent) { cont_extent[0] = buf[4 * (size_t)n1] / n; cont_extent[1] = buf[4 * (size_t)n1 + 1] / n; }
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_gbar_mean(sac_edge_t *h, double *gbar_mean)
+{
+    if (!h || !gbar_mean) return efail(SAC_E_INVALID, "sac_edge_get_gbar_mean: null argument");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const size_t nt = (size_t)h->cfg.n_tau;
+    double n = (double)h->cfg.n_chains;
+    if (h->comm && h->comm->merged) {                                // summed over all ranks' chains (edge_comm_merge)
+        HIP_TRY(hipMemcpy(gbar_mean, h->comm->dSum + h->off_gbar(), nt * sizeof(double), hipMemcpyDeviceToHost));
+        n = h->comm->hTail[42];
+    } else {
+        hipLaunchKernelGGL(edge_gbar_sum_kernel, dim3(1), dim3(SAC_MAX_N_TAU), 0, h->stream, (const double *)h->dGbar,
+                           h->cfg.n_chains, h->dGbarSum);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(gbar_mean, h->dGbarSum, nt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    for (size_t t = 0; t < nt; ++t) gbar_mean[t] = gbar_mean[t] / n;
     return SAC_OK;
 }
 

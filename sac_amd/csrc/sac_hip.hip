@@ -21,6 +21,7 @@
 #include "peak_sweep.h"
 #include "table_build.h"
 #include "cv_score.h"
+#include "comm.h"
 
 using namespace sacdev;
 
@@ -646,6 +647,82 @@ __global__ void hist_sum_kernel(const double *hist, long long n_grid, int copies
     dst[i] = s;
 }
 
+// dst[t] = sum over chains of Gbar[c][t], chains in index order (sac_get_gbar_mean; the merge payload)
+__global__ void gbar_sum_kernel(const double *gbar, int n_chains, double *dst)
+{
+    const int t = (int)threadIdx.x;
+    if (t >= SAC_MAX_N_TAU) return;
+    double s = 0.0;
+    for (int c = 0; c < n_chains; ++c) s = s + gbar[(size_t)c * SAC_MAX_N_TAU + t];
+    dst[t] = s;
+}
+
+// peak:1159-1165 per chain: mean edge of the sample stage, running sums of the means and of their squares
+__global__ void peak_edge_rows_kernel(const PeakScalars *sc, double *rows, int n_chains, double steps, int sample_neg)
+{
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_chains) return;
+    double *e = rows + (size_t)c * 6;
+    for (int pn = 0; pn < 2; ++pn) {
+        e[0 + pn] = sc[c].edge_sum[pn] / steps;
+        e[2 + pn] += e[0 + pn];
+        e[4 + pn] += e[0 + pn] * e[0 + pn];
+    }
+    if (!sample_neg) { e[1] = e[0]; e[3] = e[2]; e[5] = e[4]; }
+}
+
+// ---- per-stage merge over ranks (comm.h): this rank's sums over its chains, one thread per scalar slot, chains in
+// index order (the order sac_get_stats uses on the host, so one rank alone reproduces it bit for bit) -------------------
+constexpr int FREE_SLOTS = 20;      // <chi2>, rates[6], windows[4], sum chi2_min, counters[5], sweeps, chains, spare
+constexpr int PEAK_SLOTS = 46;      // <chi2>, rates[11], windows[11], edge_res[6], bounds[4], weights[4], sum chi2_min,
+                                    // counters[5], sweeps, chains, spare
+
+__global__ void free_pack_kernel(const ChainScalars *sc, int n_chains, double steps, int sampled, double *out_sum, double *out_min)
+{
+    const int t = (int)threadIdx.x;
+    if (t >= FREE_SLOTS) return;
+    double s = 0.0, mn = sc[0].chi2_min;
+    for (int c = 0; c < n_chains; ++c) {
+        const ChainScalars &x = sc[c];
+        double v = 0.0;
+        if (t == 0) v = sampled ? x.sum_chi2 / steps : 0.0;
+        else if (t <= 6) v = sampled ? x.acc[t - 1] / steps : x.acc[t - 1];
+        else if (t <= 10) v = x.windows[t - 7];
+        else if (t == 11) { v = x.chi2_min; if (x.chi2_min < mn) mn = x.chi2_min; }
+        else if (t <= 16) v = (double)x.counters[t - 12];
+        else if (t == 17) v = (double)x.sweep;
+        else if (t == 18) v = 1.0;
+        s = s + v;
+    }
+    out_sum[t] = s;
+    if (t == 11) out_min[0] = mn;
+}
+
+__global__ void peak_pack_kernel(const PeakScalars *sc, const double *edge_rows, const double *weights, int n_chains, double steps,
+                                 int sampled, double *out_sum, double *out_min)
+{
+    const int t = (int)threadIdx.x;
+    if (t >= PEAK_SLOTS) return;
+    double s = 0.0, mn = sc[0].chi2_min;
+    for (int c = 0; c < n_chains; ++c) {
+        const PeakScalars &x = sc[c];
+        double v = 0.0;
+        if (t == 0) v = sampled ? x.sum_chi2 / steps : 0.0;
+        else if (t <= 11) v = sampled ? x.acc[t - 1] / steps : x.acc[t - 1];
+        else if (t <= 22) v = x.windows[t - 12];
+        else if (t <= 28) v = edge_rows[(size_t)c * 6 + (t - 23)];
+        else if (t <= 32) v = (double)x.bounds[t - 29];
+        else if (t <= 36) v = weights[(size_t)c * 4 + (t - 33)];
+        else if (t == 37) { v = x.chi2_min; if (x.chi2_min < mn) mn = x.chi2_min; }
+        else if (t <= 42) v = (double)x.counters[t - 38];
+        else if (t == 43) v = (double)x.sweep;
+        else if (t == 44) v = 1.0;
+        s = s + v;
+    }
+    out_sum[t] = s;
+    if (t == 37) out_min[0] = mn;
+}
+
 // =========================================================================================
 // Host side
 // =========================================================================================
@@ -741,7 +818,10 @@ struct sac_handle {
     PeakScalars *dPsc = nullptr;
     double *dWeights = nullptr;    // [n_chains][4] group weight sums
     bool sample_neg = false, indiv_update = false, binned = false;
-    std::vector<double> edge_rows; // [n_chains][3][2]: peak:74 edge_res per chain
+    std::vector<double> edge_rows; // [n_chains][3][2]: peak:74 edge_res per chain (host mirror of dEdgeRows)
+    double *dEdgeRows = nullptr;   // the same on the device (peak_edge_rows_kernel)
+    double *dGbarSum = nullptr;    // [128] sac_get_gbar_mean without a communicator
+    saccomm::Comm *comm = nullptr; // sac_comm_init: per-stage merge over ranks
     int last_stage = 0;            // 0 none, 1 adjust_windows, 2 sample
     int64_t last_steps = 0;
     double last_stage_ms = 0.0, last_kernel_ms = 0.0;
@@ -750,6 +830,12 @@ struct sac_handle {
 };
 
 extern "C" const char *sac_last_error(void) { return g_err; }
+
+// host code changed the chains: the merged view of the last stage (comm_merge) no longer describes them
+static void drop_merged(sac_handle *h)
+{
+    if (h->comm) h->comm->merged = false;
+}
 
 static int use_device(sac_handle *h)
 {
@@ -843,8 +929,10 @@ extern "C" int sac_create(const sac_config_t *cfg, sac_handle_t **out)
         ALLOC(h->dPsc, nc * sizeof(PeakScalars));
         ALLOC(h->dWeights, nc * 4 * sizeof(double));
         h->edge_rows.assign(nc * 6, 0.0);
+        ALLOC(h->dEdgeRows, nc * 6 * sizeof(double));
     }
     ALLOC(h->dLogLen, sizeof(unsigned long long));
+    ALLOC(h->dGbarSum, SAC_MAX_N_TAU * sizeof(double));
 #undef ALLOC
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) {
@@ -863,7 +951,9 @@ extern "C" int sac_destroy(sac_handle_t *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->dK); hipFree(h->dG); hipFree(h->dSinv); hipFree(h->dWi); hipFree(h->dA);
     hipFree(h->dGbar); hipFree(h->dSc); hipFree(h->dHist); hipFree(h->dLog); hipFree(h->dLogLen);
-    hipFree(h->dKn); hipFree(h->dPsc); hipFree(h->dWeights);
+    hipFree(h->dKn); hipFree(h->dPsc); hipFree(h->dWeights); hipFree(h->dEdgeRows); hipFree(h->dGbarSum);
+    saccomm::destroy(h->comm);
+    h->comm = nullptr;
     for (auto &pr : h->kev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1014,6 +1104,7 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
     int first, count, rc;
     if ((rc = chain_range(h, chain, &first, &count, "sac_set_state"))) return rc;
     if ((rc = use_device(h))) return rc;
+    drop_merged(h);
     const int n = h->n_state;
     if (wi) {
         std::vector<uint32_t> rel((size_t)h->wi_stride, 0u);
@@ -1123,6 +1214,8 @@ static unsigned grid_blocks(const sac_handle *h)
     return (unsigned)((h->cfg.n_chains + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
 }
 
+static int comm_merge(sac_handle *h);
+__global__ void peak_weights_kernel(const double *A, int stride, int n_chains, int n_p, int n, double *out);
 static int peak_init(sac_handle *h);
 static int peak_adjust_windows(sac_handle *h, int64_t steps, double theta);
 static int peak_sample(sac_handle *h, int64_t steps, double theta, bool bin);
@@ -1145,7 +1238,8 @@ extern "C" int sac_init_gbar(sac_handle_t *h)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->gbar_set = true;
-    return SAC_OK;
+    h->last_stage = 0;
+    return comm_merge(h);
 }
 
 extern "C" int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double *chi2, double *chi2_min)
@@ -1173,6 +1267,28 @@ extern "C" int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double
     return SAC_OK;
 }
 
+extern "C" int sac_get_gbar_mean(sac_handle_t *h, double *gbar_mean)
+{
+    if (!h || !gbar_mean) return fail(SAC_E_INVALID, "sac_get_gbar_mean: null argument");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const size_t nt = (size_t)h->cfg.n_tau;
+    double n = (double)h->cfg.n_chains;
+    if (h->comm && h->comm->merged && h->last_stage == 2) {           // summed over all ranks' chains (comm_merge)
+        const size_t n_hist = (size_t)h->cfg.n_grid * (size_t)h->hist_arrays;
+        HIP_TRY(hipMemcpy(gbar_mean, h->comm->dSum + n_hist, nt * sizeof(double), hipMemcpyDeviceToHost));
+        n = h->comm->hTail[h->peak ? 44 : 18];
+    } else {
+        hipLaunchKernelGGL(gbar_sum_kernel, dim3(1), dim3(SAC_MAX_N_TAU), 0, h->stream, (const double *)h->dGbar, h->cfg.n_chains,
+                           h->dGbarSum);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(gbar_mean, h->dGbarSum, nt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    for (size_t t = 0; t < nt; ++t) gbar_mean[t] = gbar_mean[t] / n;
+    return SAC_OK;
+}
+
 extern "C" int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, double chi2, double chi2_min)
 {
     if (!h || !gbar) return fail(SAC_E_INVALID, "sac_set_gbar: null argument");
@@ -1180,6 +1296,7 @@ extern "C" int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, 
     int first, count, rc;
     if ((rc = chain_range(h, chain, &first, &count, "sac_set_gbar"))) return rc;
     if ((rc = use_device(h))) return rc;
+    drop_merged(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::vector<double> pad(SAC_MAX_N_TAU, 0.0);
     std::memcpy(pad.data(), gbar, (size_t)h->cfg.n_tau * sizeof(double));
@@ -1353,6 +1470,39 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
     return SAC_OK;
 }
 
+// The per-stage merge over ranks (include/sac_hip.h "multi-GPU merge"): this rank's histogram replicas summed into the
+// payload, its scalar sums packed behind them, ONE all-reduce(sum) + ONE all-reduce(min), merged scalars read back.
+static int comm_merge(sac_handle *h)
+{
+    if (!h->comm) return SAC_OK;
+    saccomm::Comm *c = h->comm;
+    const int nc = h->cfg.n_chains;
+    const long long n_hist = (long long)h->cfg.n_grid * h->hist_arrays, n_pay = n_hist + SAC_MAX_N_TAU;   // [hist | sum of Gbar]
+    const bool sampled = (h->last_stage == 2);
+    const double steps = (double)h->last_steps;
+    if (sampled) {
+        hipLaunchKernelGGL(hist_sum_kernel, dim3((unsigned)((n_hist + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double *)h->dHist, n_hist, h->hist_copies, c->dSum);
+        hipLaunchKernelGGL(gbar_sum_kernel, dim3(1), dim3(SAC_MAX_N_TAU), 0, h->stream, (const double *)h->dGbar, nc, c->dSum + n_hist);
+        HIP_TRY(hipGetLastError());
+    }
+    if (h->peak) {
+        hipLaunchKernelGGL(peak_weights_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, h->stream,
+                           (const double *)h->dA, h->wi_stride, nc, h->cfg.n_peak, h->cfg.n_omega, h->dWeights);
+        hipLaunchKernelGGL(peak_pack_kernel, dim3(1), dim3(64), 0, h->stream, (const PeakScalars *)h->dPsc,
+                           (const double *)h->dEdgeRows, (const double *)h->dWeights, nc, steps, sampled ? 1 : 0,
+                           c->dSum + n_pay, c->dMin);
+    } else {
+        hipLaunchKernelGGL(free_pack_kernel, dim3(1), dim3(64), 0, h->stream, (const ChainScalars *)h->dSc, nc, steps,
+                           sampled ? 1 : 0, c->dSum + n_pay, c->dMin);
+    }
+    HIP_TRY(hipGetLastError());
+    char msg[256];
+    if (saccomm::merge(c, (size_t)n_pay, sampled, h->stream, msg, sizeof(msg)))
+        return fail(SAC_E_HIP, "merge over ranks: %s", msg);
+    return SAC_OK;
+}
+
 static int stage_begin(sac_handle *h, const char *who, int64_t steps, double theta)
 {
     if (!h) return fail(SAC_E_INVALID, "%s: null handle", who);
@@ -1363,6 +1513,7 @@ static int stage_begin(sac_handle *h, const char *who, int64_t steps, double the
     int rc;
     if ((rc = use_device(h))) return rc;
     h->last_launches = 0;
+    drop_merged(h);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     return SAC_OK;
 }
@@ -1485,7 +1636,8 @@ static int peak_init(sac_handle *h)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->gbar_set = true;
-    return SAC_OK;
+    h->last_stage = 0;
+    return comm_merge(h);
 }
 
 static int run_peak_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_all, int flags_first,
@@ -1554,7 +1706,8 @@ static int peak_adjust_windows(sac_handle *h, int64_t steps, double theta)
     for (int round = 0; round < 10; ++round)                         // peak:1066-1093
         if ((rc = run_peak_sweeps(h, per, theta, 0, STAGE_ZERO_ACC, STAGE_RETUNE, (double)per, true, true)))
             return rc;
-    return stage_end(h, 1, steps);
+    if ((rc = stage_end(h, 1, steps))) return rc;
+    return comm_merge(h);
 }
 
 static int peak_sample(sac_handle *h, int64_t steps, double theta, bool bin)
@@ -1573,18 +1726,12 @@ static int peak_sample(sac_handle *h, int64_t steps, double theta, bool bin)
     if ((rc = stage_end(h, 2, steps))) return rc;
     // peak:1159-1165: per-chain edge means, and the running sums of means and squares
     const int nc = h->cfg.n_chains;
-    std::vector<PeakScalars> sc((size_t)nc);
-    HIP_TRY(hipMemcpy(sc.data(), h->dPsc, (size_t)nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
-    for (int c = 0; c < nc; ++c) {
-        double *e = h->edge_rows.data() + (size_t)c * 6;
-        for (int pn = 0; pn < 2; ++pn) {
-            e[0 + pn] = sc[(size_t)c].edge_sum[pn] / (double)steps;
-            e[2 + pn] += e[0 + pn];
-            e[4 + pn] += e[0 + pn] * e[0 + pn];
-        }
-        if (!h->sample_neg) { e[1] = e[0]; e[3] = e[2]; e[5] = e[4]; }
-    }
-    return SAC_OK;
+    hipLaunchKernelGGL(peak_edge_rows_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream,
+                       (const PeakScalars *)h->dPsc, h->dEdgeRows, nc, (double)steps, h->sample_neg ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->edge_rows.data(), h->dEdgeRows, (size_t)nc * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return comm_merge(h);
 }
 
 extern "C" int sac_sample_bin(sac_handle_t *h, int64_t steps, double theta)
@@ -1607,9 +1754,11 @@ extern "C" int sac_zero_accumulators(sac_handle_t *h)
     if (!h || !h->peak) return fail(SAC_E_INVALID, "sac_zero_accumulators: not a SAC_KIND_PEAK handle");
     int rc;
     if ((rc = use_device(h))) return rc;
+    drop_merged(h);
     HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * 4 * (size_t)h->cfg.n_grid * sizeof(double), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::fill(h->edge_rows.begin(), h->edge_rows.end(), 0.0);
+    HIP_TRY(hipMemset(h->dEdgeRows, 0, h->edge_rows.size() * sizeof(double)));
     h->binned = true;
     return SAC_OK;
 }
@@ -1657,6 +1806,24 @@ extern "C" int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out)
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->comm && h->comm->merged) {                                // the values over all ranks (comm_merge)
+        const double *t = h->comm->hTail;
+        const double n = t[44];
+        std::memset(out, 0, sizeof(*out));
+        out->sampled_chi2 = t[0] / n;
+        for (int k = 0; k < 11; ++k) { out->accept_rates[k] = t[1 + k] / n; out->windows[k] = t[12 + k] / n; }
+        for (int k = 0; k < 6; ++k) (&out->edge_res[0][0])[k] = t[23 + k] / n;
+        for (int k = 0; k < 4; ++k) { out->bounds[k] = t[29 + k] / n; out->weights[k] = t[33 + k] / n; }
+        out->chi2_min_mean = t[37] / n;
+        out->chi2_min = t[PEAK_SLOTS];
+        out->proposals = (uint64_t)t[38]; out->evaluated = (uint64_t)t[39]; out->accepted = (uint64_t)t[40];
+        out->accepted_moves = (uint64_t)t[41]; out->columns_gathered = (uint64_t)t[42]; out->sweeps = (uint64_t)t[43];
+        out->n_chains_total = (int64_t)n;
+        out->last_stage_ms = h->last_stage_ms;
+        out->last_kernel_ms = h->last_kernel_ms;
+        out->last_kernel_launches = h->last_launches;
+        return SAC_OK;
+    }
     const int nc = h->cfg.n_chains;
     std::vector<PeakScalars> sc((size_t)nc);
     HIP_TRY(hipMemcpy(sc.data(), h->dPsc, (size_t)nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
@@ -1679,6 +1846,7 @@ extern "C" int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out)
         for (int k = 0; k < 4; ++k) { out->bounds[k] += (double)s.bounds[k]; out->weights[k] += wts[(size_t)c * 4 + k]; }
         for (int k = 0; k < 6; ++k) (&out->edge_res[0][0])[k] += h->edge_rows[(size_t)c * 6 + k];
         if (s.chi2_min < cmin) cmin = s.chi2_min;
+        out->chi2_min_mean += s.chi2_min;
         out->proposals += s.counters[0];
         out->evaluated += s.counters[1];
         out->accepted += s.counters[2];
@@ -1687,6 +1855,8 @@ extern "C" int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out)
         out->sweeps += s.sweep;
     }
     out->sampled_chi2 /= dn;
+    out->chi2_min_mean /= dn;
+    out->n_chains_total = nc;
     out->chi2_min = cmin;
     for (int k = 0; k < 11; ++k) { out->accept_rates[k] /= dn; out->windows[k] /= dn; }
     for (int k = 0; k < 4; ++k) { out->bounds[k] /= dn; out->weights[k] /= dn; }
@@ -1705,6 +1875,12 @@ extern "C" int sac_get_histogram_peak(sac_handle_t *h, int32_t which, double *ou
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ng = (size_t)h->cfg.n_grid;
+    if (h->comm && h->comm->merged && h->last_stage == 2) {           // summed over all ranks' chains (comm_merge)
+        HIP_TRY(hipMemcpy(out, h->comm->dSum + (size_t)which * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
+        const double n = h->comm->hTail[44], div = h->binned ? 1.0 : (double)h->last_steps;
+        for (size_t i = 0; i < ng; ++i) out[i] = out[i] / div / n;
+        return SAC_OK;
+    }
     std::vector<double> tmp(ng);
     std::fill(out, out + ng, 0.0);
     for (int c = 0; c < h->hist_copies; ++c) {
@@ -1729,7 +1905,8 @@ extern "C" int sac_adjust_windows(sac_handle_t *h, int64_t steps, double theta)
         // per == 0 still runs the (empty) launch so that 0/0 = NaN leaves the windows alone.
         if ((rc = run_sweeps(h, per, theta, 0, STAGE_ZERO_ACC, STAGE_RETUNE, (double)per))) return rc;
     }
-    return stage_end(h, 1, steps);
+    if ((rc = stage_end(h, 1, steps))) return rc;
+    return comm_merge(h);
 }
 
 extern "C" int sac_sample(sac_handle_t *h, int64_t steps, double theta)
@@ -1740,7 +1917,8 @@ extern "C" int sac_sample(sac_handle_t *h, int64_t steps, double theta)
     HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * (size_t)h->cfg.n_grid * sizeof(double),
                            h->stream));                             // free:906
     if ((rc = run_sweeps(h, steps, theta, STAGE_SAMPLE, STAGE_ZERO_ACC, 0, 1.0))) return rc;
-    return stage_end(h, 2, steps);
+    if ((rc = stage_end(h, 2, steps))) return rc;
+    return comm_merge(h);
 }
 
 extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
@@ -1750,12 +1928,29 @@ extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->comm && h->comm->merged) {                                // the values over all ranks (comm_merge)
+        const double *t = h->comm->hTail;
+        const double n = t[18];
+        std::memset(out, 0, sizeof(*out));
+        out->sampled_chi2 = t[0] / n;
+        for (int k = 0; k < 6; ++k) out->accept_rates[k] = t[1 + k] / n;
+        for (int k = 0; k < 4; ++k) out->windows[k] = t[7 + k] / n;
+        out->chi2_min_mean = t[11] / n;
+        out->chi2_min = t[FREE_SLOTS];
+        out->proposals = (uint64_t)t[12]; out->evaluated = (uint64_t)t[13]; out->accepted = (uint64_t)t[14];
+        out->accepted_moves = (uint64_t)t[15]; out->columns_gathered = (uint64_t)t[16]; out->sweeps = (uint64_t)t[17];
+        out->n_chains_total = (int64_t)n;
+        out->last_stage_ms = h->last_stage_ms;
+        out->last_kernel_ms = h->last_kernel_ms;
+        out->last_kernel_launches = h->last_launches;
+        return SAC_OK;
+    }
     const int nc = h->cfg.n_chains;
     std::vector<ChainScalars> sc((size_t)nc);
     HIP_TRY(hipMemcpy(sc.data(), h->dSc, (size_t)nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     const double steps = (double)h->last_steps;
-    double s_chi2 = 0.0, ar[6] = {0, 0, 0, 0, 0, 0}, win[4] = {0, 0, 0, 0};
+    double s_chi2 = 0.0, cmm = 0.0, ar[6] = {0, 0, 0, 0, 0, 0}, win[4] = {0, 0, 0, 0};
     double cmin = sc[0].chi2_min;
     for (int c = 0; c < nc; ++c) {
         const ChainScalars &s = sc[(size_t)c];
@@ -1767,6 +1962,7 @@ extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
         }
         for (int k = 0; k < 4; ++k) win[k] += s.windows[k];
         if (s.chi2_min < cmin) cmin = s.chi2_min;
+        cmm += s.chi2_min;
         out->proposals += s.counters[0];
         out->evaluated += s.counters[1];
         out->accepted += s.counters[2];
@@ -1775,6 +1971,8 @@ extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
         out->sweeps += s.sweep;
     }
     out->sampled_chi2 = s_chi2 / (double)nc;
+    out->chi2_min_mean = cmm / (double)nc;
+    out->n_chains_total = nc;
     out->chi2_min = cmin;
     for (int k = 0; k < 6; ++k) out->accept_rates[k] = ar[k] / (double)nc;
     for (int k = 0; k < 4; ++k) out->windows[k] = win[k] / (double)nc;
@@ -1967,6 +2165,7 @@ extern "C" int sac_copy_chain(sac_handle_t *h, int32_t src, int32_t dst)
     if (src == dst) return SAC_OK;
     int rc;
     if ((rc = use_device(h))) return rc;
+    drop_merged(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ws = (size_t)h->wi_stride;
     HIP_TRY(hipMemcpy(h->dWi + dst * ws, h->dWi + src * ws, ws * sizeof(uint32_t), hipMemcpyDeviceToDevice));
@@ -2009,6 +2208,12 @@ extern "C" int sac_get_histogram(sac_handle_t *h, double *out)
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ng = (size_t)h->cfg.n_grid;
+    if (h->comm && h->comm->merged) {                                // summed over all ranks' chains (comm_merge)
+        HIP_TRY(hipMemcpy(out, h->comm->dSum, ng * sizeof(double), hipMemcpyDeviceToHost));
+        const double steps = (double)h->last_steps, n = h->comm->hTail[18];
+        for (size_t i = 0; i < ng; ++i) out[i] = out[i] / steps / n;
+        return SAC_OK;
+    }
     std::vector<double> tmp(ng);
     HIP_TRY(hipMemcpy(out, h->dHist, ng * sizeof(double), hipMemcpyDeviceToHost));
     for (int c = 1; c < h->hist_copies; ++c) {
@@ -2042,6 +2247,43 @@ extern "C" int sac_get_histogram_sum_device(sac_handle_t *h, void *dst_device, d
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (steps_times_chains) *steps_times_chains = (double)h->last_steps * (double)h->cfg.n_chains;
+    return SAC_OK;
+}
+
+extern "C" int sac_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(SAC_E_INVALID, "sac_comm_unique_id: null argument");
+    saccomm::Api &a = saccomm::api();
+    if (!a.lib) return fail(SAC_E_STATE, "sac_comm_unique_id: RCCL is not available: %s", a.why);
+    saccomm::UniqueId id;
+    const int rc = a.GetUniqueId(&id);
+    if (rc != 0) return fail(SAC_E_HIP, "ncclGetUniqueId: %s", a.GetErrorString(rc));
+    static_assert(sizeof(id) == SAC_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return SAC_OK;
+}
+
+extern "C" int sac_comm_init(sac_handle_t *h, const void *id128, int32_t rank, int32_t world)
+{
+    if (!h || !id128) return fail(SAC_E_INVALID, "sac_comm_init: null argument");
+    if (h->comm) return fail(SAC_E_STATE, "sac_comm_init: the handle has a communicator already");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    char msg[320];
+    h->comm = saccomm::create(id128, rank, world, (size_t)h->cfg.n_grid * (size_t)h->hist_arrays + SAC_MAX_N_TAU,
+                              h->peak ? PEAK_SLOTS : FREE_SLOTS, 1, msg, sizeof(msg));
+    if (!h->comm) return fail(SAC_E_HIP, "sac_comm_init: %s", msg);
+    return SAC_OK;
+}
+
+extern "C" int sac_comm_info(sac_handle_t *h, int32_t *rank, int32_t *world, int64_t *merges, int64_t *allreduce_calls)
+{
+    if (!h) return fail(SAC_E_INVALID, "sac_comm_info: null handle");
+    if (rank) *rank = h->comm ? h->comm->rank : 0;
+    if (world) *world = h->comm ? h->comm->world : 1;
+    if (merges) *merges = h->comm ? h->comm->merges : 0;
+    if (allreduce_calls) *allreduce_calls = h->comm ? h->comm->allreduce_calls : 0;
     return SAC_OK;
 }
 

@@ -1,6 +1,13 @@
 """Multi-GPU merge for the sampling stages: one process per GPU (torch.distributed; backend
 "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
 
+With the "nccl" backend the merge itself lives BEHIND the C ABI (sac_comm_init / sac_edge_comm_init,
+include/sac_hip.h): `Comm.attach(handle)` hands the handle an RCCL communicator, every stage call then ends
+with one fused ncclAllReduce(sum) + one ncclAllReduce(min) on the handle's stream, and the handle's reduced
+getters answer for all ranks -- this module only carries the 128-byte unique id to the ranks.  The torch
+collectives below remain for host-side groups (gloo: the CPU tests, several ranks sharing one GPU) and for
+what is not a stage statistic.
+
 The path shards: independent chains are block-partitioned over ranks (the Philox key carries the
 global chain id, so a chain's trajectory does not depend on the rank count) and no collective
 runs inside a stage.  After a stage every rank holds partial sums; ONE fused all-reduce(sum) of
@@ -30,11 +37,27 @@ class Comm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = torch.device(device)
+        # the merge can go behind the C ABI when the ranks own one GPU each and talk RCCL
+        self.abi = self.device.type == "cuda" and dist.get_backend(group) == "nccl"
 
-    def merge_scalars(self, n_chains, sampled_chi2, chi2_min, accept_rates, windows):
+    def attach(self, handle):
+        """Puts the per-stage merge of `handle` (SacHandle / SacEdgeHandle) behind the C ABI: rank 0 draws the RCCL
+        unique id (sac_comm_unique_id), every rank joins with sac_comm_init.  Collective.  Returns False (and leaves the
+        torch path in charge) for host-side groups."""
+        if not self.abi:
+            return False
+        from .lib import comm_unique_id
+        box = [comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group, device=self.device)
+        handle.comm_init(box[0], self.rank, self.world)
+        return True
+
+    def merge_scalars(self, n_chains, sampled_chi2, chi2_min, accept_rates, windows, chi2_min_mean=None):
         """Chain-weighted means (min for chi2_min) over all ranks."""
+        cmm = chi2_min if chi2_min_mean is None else chi2_min_mean
         buf = torch.tensor([sampled_chi2 * n_chains, *[a * n_chains for a in accept_rates],
-                            *[w * n_chains for w in windows], float(n_chains)],
+                            *[w * n_chains for w in windows], cmm * n_chains, float(n_chains)],
                            dtype=torch.float64, device=self.device)
         mn = torch.tensor([chi2_min], dtype=torch.float64, device=self.device)
         dist.all_reduce(buf, group=self.group)
@@ -43,7 +66,8 @@ class Comm:
         n = float(buf[-1])
         return SimpleNamespace(sampled_chi2=float(buf[0]) / n, chi2_min=float(mn.cpu()[0]),
                                accept_rates=[float(x) / n for x in buf[1:7]],
-                               windows=[float(x) / n for x in buf[7:11]], n_chains=int(n))
+                               windows=[float(x) / n for x in buf[7:11]], chi2_min_mean=float(buf[11]) / n,
+                               n_chains=int(n), n_chains_total=int(n))
 
     def merge_named(self, n_chains, means, mins=None, sums=None):
         """Generic per-stage merge used by the peak and edge drivers: `means` are this rank's
@@ -88,7 +112,7 @@ class Comm:
         """st: sac_stats_t-like (sampled_chi2, chi2_min, accept_rates[6], windows[4])."""
         n = n_chains if n_chains is not None else getattr(st, "n_chains", 1)
         return self.merge_scalars(n, st.sampled_chi2, st.chi2_min, list(st.accept_rates)[:6],
-                                  list(st.windows)[:4])
+                                  list(st.windows)[:4], getattr(st, "chi2_min_mean", None))
 
     def merge_histogram_sum(self, hist_sum, divisor):
         """hist_sum: this rank's un-normalised histogram (tensor on self.device); divisor: its

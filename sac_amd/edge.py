@@ -226,11 +226,17 @@ class EdgeProblem:
 
 class EdgeSAC:
     """The reference's SAC struct + schedule functions for the edge parameterisation (edge:1452-2065).
-    With n_chains > 1 every printed statistic is the mean over chains (chi2_min: the minimum)."""
+    With n_chains > 1 every printed statistic is the mean over chains; chi2_min, which the reference's criteria take from
+    its ONE chain (edge:1682, 1718), is by default the mean over chains of each chain's own minimum (chi2_min_mode=
+    "chain_mean": Theta_opt then does not drift with the number of chains), or the minimum over all chains ("min")."""
 
     def __init__(self, N_e, N_c, omega_0, omega_m, d_omega_h, d_omega, p, A_c, A_r, theta_0, f_anneal, N_anneal,
                  a_criterion, anneal_steps, sample_steps, bins, G_file, output_folder, fix_edge, kernel_type, mode,
-                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None, spread_sampling=False):
+                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None, spread_sampling=False,
+                 chi2_min_mode="chain_mean"):
+        if chi2_min_mode not in ("chain_mean", "min"):
+            raise ValueError("chi2_min_mode must be 'chain_mean' or 'min'")
+        self.chi2_min_mode = chi2_min_mode
         self.comm = comm
         # no counterpart in the one-chain reference: the final sampling's sweeps per bin are shared out over all chains
         self.spread_sampling = bool(spread_sampling)
@@ -338,52 +344,64 @@ class EdgeSAC:
             self.h.close()
         offset = 0 if self.comm is None else self.comm.rank * self.n_chains
         self.h = pr.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device, chain_offset=offset)
-        self.chi2_min = self.h.get_gbar(0)[2]                               # all chains start from the same configuration
+        if self.comm is not None:
+            self.comm.attach(self.h)                                        # RCCL groups: the merge goes behind the C ABI
+        self.chi2_min = self.chi2_min_all = self.h.get_gbar(0)[2]           # all chains start from the same configuration
         self.write_log("Initialization Finished.")
 
     # ---- stage -----------------------------------------------------------------------------
     def run_bins(self, steps, bins, theta):                                 # edge:1357
         self.h.run_bins(steps, bins, theta)
-        self.res = self.h.results(-1)
-        if self.comm is not None:                                           # one all-reduce per stage
+        self.res = self.h.results(-1)                                       # over all ranks already when the handle merges
+        if self.comm is not None and not self.h.merged_over_ranks:          # host-side groups: one all-reduce per stage
             r = self.res
-            keys = ("chi2_res", "edge_res", "n0_res", "wn0_res", "amp_ar", "n0", "eps0", "dn0", "deps0", "chi2")
+            keys = ("chi2_res", "edge_res", "n0_res", "wn0_res", "amp_ar", "n0", "eps0", "dn0", "deps0", "chi2", "chi2_min_mean")
             m = self.comm.merge_named(self.n_chains, {k: r[k] for k in keys}, mins={"chi2_min": r["chi2_min"]},
                                       sums={"violations": r["violations"]})
             self.res = dict(r, **m)
-        self.chi2_min = self.res["chi2_min"]
+        self.chi2_min_all = self.res["chi2_min"]
+        self.chi2_min = self.res["chi2_min_mean"] if self.chi2_min_mode == "chain_mean" else self.res["chi2_min"]
         if self.res["violations"]:
             with open(self._path("error.txt"), "a") as f:                   # the reference exit()s here (edge:668)
                 f.write(f"{jl_float(theta)} ordering / bound violations in {self.res['violations']} chain-bins\n")
             raise RuntimeError("check_w: ordering or bound violation (see error.txt)")
 
-    def _chain_states(self):
-        return [self.h.get_state(c) for c in range(min(self.n_chains, 32))]
+    def _move_means(self):
+        """Chain means over ALL chains of all ranks of the per-delta windows, the cluster sizes and the continuum's extent
+        (write_res, edge:1454-1506): one call, summed on the device (sac_edge_get_move_means)."""
+        dw, nm, ext = self.h.move_means()
+        if self.comm is not None and not self.h.merged_over_ranks:          # host-side groups
+            m = self.comm.merge_named(self.n_chains, {"dw": dw, "nm": nm, "ext": ext})
+            dw, nm, ext = m["dw"], m["nm"], m["ext"]
+        return dw, nm, ext
 
     def _hist(self, which, rl):
         h = self.h.histogram(which, rl)
-        if self.comm is None:
+        if self.comm is None or self.h.merged_over_ranks:
             return h
         tot = self.comm.sum_vector(np.concatenate([h * self.n_chains, [float(self.n_chains)]]))
         return tot[:-1] / tot[-1]
 
+    def _accept_rates(self, m, rl):
+        a = self.h.accept_rates(m, rl)
+        if self.comm is None or self.h.merged_over_ranks:
+            return a
+        return self.comm.merge_named(self.n_chains, {"a": a})["a"]
+
     def _avg(self):
         w, A = self.h.avg(-1)
-        if self.comm is None:
+        if self.comm is None or self.h.merged_over_ranks:
             return w, A
         m = self.comm.merge_named(self.n_chains, {"w": w, "A": A})
         return m["w"], m["A"]
 
     def write_res(self, j, theta):                                          # edge:1452-1510
+        r, NE, N, nt = self.res, self.N_e, self.prob.n_omega, self.td.n_tau
+        dwm, nmm, ext = self._move_means()                                  # collective for host-side groups: every rank
+        ar = {rl: (self._accept_rates(0, rl), self._accept_rates(1, rl)) for rl in self.prob.rls}
         if not self.is_root:
             return
-        r, NE, N, nt = self.res, self.N_e, self.prob.n_omega, self.td.n_tau
-        states = self._chain_states()
-        if self.A_c > 0:
-            w_c0 = float(np.mean([s["w"][NE + 1:, 0].min() for s in states]))
-            w_cf = float(np.mean([s["w"][NE + 1:, 0].max() for s in states]))
-        else:
-            w_c0 = w_cf = 0.0
+        w_c0, w_cf = (float(ext[0]), float(ext[1])) if self.A_c > 0 else (0.0, 0.0)
         vals = [theta, self.chi2_min / nt, r["chi2_res"][1] / nt, r["chi2_res"][2] / nt,
                 r["edge_res"][1, 0], r["wn0_res"][1, 0], r["n0_res"][1, 0], r["eps0"][0],
                 r["edge_res"][2, 0], r["wn0_res"][2, 0], r["n0_res"][2, 0],
@@ -391,10 +409,8 @@ class EdgeSAC:
                 r["edge_res"][2, 1], r["wn0_res"][2, 1], r["n0_res"][2, 1], w_c0, w_cf]
         with open(self._path("anneal.csv"), "a") as f:
             f.write(f"{j}," + ",".join(jl_float(_jl_round(v, 8)) for v in vals) + "\n")
-        dwm = np.mean([s["dw"] for s in states], axis=0)
-        nmm = np.mean([s["nm"] for s in states], axis=0)
         for rl in self.prob.rls:
-            ar1, ar2 = self.h.accept_rates(0, rl), self.h.accept_rates(1, rl)
+            ar1, ar2 = ar[rl]
             nc = N - NE
             with np.errstate(divide="ignore", invalid="ignore"):
                 a1 = np.float64(ar1[NE + 1:].sum()) / nc                    # Julia: 0/0 -> NaN without continuum
@@ -537,6 +553,7 @@ class EdgeSAC:
         return theta_opt
 
     def _sample_row(self, j, theta, with_cont):
+        ext = self._move_means()[2] if (with_cont and self.A_c > 0) else (0.0, 0.0)   # collective for host-side groups
         if not self.is_root:
             return
         r, NE, nt = self.res, self.N_e, self.td.n_tau
@@ -546,12 +563,7 @@ class EdgeSAC:
                 -r["edge_res"][1, 1], -r["wn0_res"][1, 1], r["n0_res"][1, 1], r["eps0"][1],
                 r["edge_res"][2, 1], r["wn0_res"][2, 1], r["n0_res"][2, 1]]
         if with_cont:
-            if self.A_c > 0:
-                states = self._chain_states()
-                vals += [float(np.mean([s["w"][NE + 1:, 0].min() for s in states])),
-                         float(np.mean([s["w"][NE + 1:, 0].max() for s in states]))]
-            else:
-                vals += [0.0, 0.0]
+            vals += [float(ext[0]), float(ext[1])] if self.A_c > 0 else [0.0, 0.0]
         with open(self._path("sample.csv"), "a") as f:
             f.write(f"{j}," + ",".join(jl_float(_jl_round(v, 8)) for v in vals) + "\n")
 

@@ -125,13 +125,21 @@ class FreeSAC:
     """The reference's SAC struct + schedule functions for the `free` parameterisation, with the
     fixed-Theta stages (adjust_windows, sample) running on the GPU behind the C ABI.
 
-    With n_chains > 1 every stage statistic is the mean (chi2_min: the minimum) over chains, and
-    with a torch.distributed process group the per-stage merge is one all-reduce (dist.py), so all
-    ranks take the same schedule decisions."""
+    With n_chains > 1 every stage statistic is the mean over chains.  chi2_min, which the reference's schedule
+    criteria take from its ONE chain (stop rule free:1087, a-values free:1128, Theta_opt free:1249-1252), is by default
+    the single-chain equivalent -- the mean over chains of each chain's own minimum (chi2_min_mode="chain_mean"), so
+    that Theta_opt does not drift with the number of chains; chi2_min_mode="min" takes the minimum over all chains (the
+    lowest chi2 any chain has seen; it lowers the target as chains are added).  self.chi2_min_all always holds that
+    minimum.  With a process group the per-stage merge is one fused all-reduce(sum) + one all-reduce(min) -- behind the
+    C ABI for RCCL groups (dist.Comm.attach) -- so all ranks take the same schedule decisions."""
 
     def __init__(self, par, N_omega, omega_0, omega_m, d_omega, d_omega_h, theta_0, f_anneal, f_final,
                  a1, a2, N_anneal, anneal_steps, sample_steps, G_file, output_folder, symm, kernel_type,
-                 n_chains=1, seed=0, tol=1e-3, device=0, comm=None, timedata=None, spread_sampling=False, device_tables=False):
+                 n_chains=1, seed=0, tol=1e-3, device=0, comm=None, timedata=None, spread_sampling=False, device_tables=False,
+                 chi2_min_mode="chain_mean"):
+        if chi2_min_mode not in ("chain_mean", "min"):
+            raise ValueError("chi2_min_mode must be 'chain_mean' or 'min'")
+        self.chi2_min_mode = chi2_min_mode
         self.par, self.N_omega = int(par), int(N_omega)
         self.omega_0, self.omega_m, self.d_omega, self.d_omega_h = float(omega_0), float(omega_m), float(d_omega), float(d_omega_h)
         self.theta_0, self.f_anneal, self.f_final = float(theta_0), float(f_anneal), float(f_final)
@@ -180,14 +188,17 @@ class FreeSAC:
         offset = 0 if self.comm is None else self.comm.rank * self.n_chains
         self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, chain_offset=offset,
                                        device=self.device, device_tables=self.device_tables)
+        if self.comm is not None:
+            self.comm.attach(self.h)                                # RCCL groups: the merge goes behind the C ABI
         self._merge()
         return self
 
     def _merge(self):
-        st = self.h.stats()
-        if self.comm is not None:
+        st = self.h.stats()                                         # over all ranks already when the handle merges
+        if self.comm is not None and not self.h.merged_over_ranks:
             st = self.comm.merge_stats(st, n_chains=self.n_chains)
-        self.sampled_chi2, self.chi2_min = st.sampled_chi2, st.chi2_min
+        self.sampled_chi2, self.chi2_min_all = st.sampled_chi2, st.chi2_min
+        self.chi2_min = st.chi2_min_mean if self.chi2_min_mode == "chain_mean" else st.chi2_min
         self.accept_rates = np.array(st.accept_rates[:])
         self.update_windows = np.array(st.windows[:])
         return st
@@ -202,7 +213,7 @@ class FreeSAC:
 
     def sampled_spec(self):
         """self.sampled_spec (free:59) merged over chains (and ranks)."""
-        if self.comm is None:
+        if self.comm is None or self.h.merged_over_ranks:
             return self.h.histogram()
         return self.comm.merge_histogram(self.h)
 
@@ -281,13 +292,11 @@ class FreeSAC:
 
     def mean_gbar(self):
         """Gbar (eigenbasis) averaged over this handle's chains (one chain: the reference's self.Gbar)."""
-        g = np.zeros(self.td.n_tau)
-        for c in range(self.n_chains):
-            g += self.h.get_gbar(c)[0][: self.td.n_tau]
-        if self.comm is not None:
-            tot = self.comm.sum_vector(np.concatenate([g, [float(self.n_chains)]]))
+        g = self.h.gbar_mean()                                      # one call: summed on the device (over ranks too when merged)
+        if self.comm is not None and not self.h.merged_over_ranks:
+            tot = self.comm.sum_vector(np.concatenate([g * self.n_chains, [float(self.n_chains)]]))
             return tot[:-1] / tot[-1]
-        return g / self.n_chains
+        return g
 
     def main_anneal(self, wr=False, on_stage=None):                 # free:1051-1094
         theta = self.theta_0

@@ -21,6 +21,7 @@ EXPORTS = [
     "sac_edge_get_move_log",
     "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
+    "sac_get_gbar_mean", "sac_edge_get_gbar_mean", "sac_edge_get_move_means", "sac_comm_unique_id", "sac_comm_init", "sac_comm_info", "sac_edge_comm_init", "sac_edge_comm_info",
     "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_set_proposals_per_step", "sac_get_proposals_per_step", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
 ]
 
@@ -49,7 +50,8 @@ class Stats(C.Structure):
                 ("accepted_moves", C.c_uint64), ("sweeps", C.c_uint64),
                 ("columns_gathered", C.c_uint64),
                 ("last_stage_ms", C.c_double), ("last_kernel_ms", C.c_double),
-                ("last_kernel_launches", C.c_int64)]
+                ("last_kernel_launches", C.c_int64),
+                ("chi2_min_mean", C.c_double), ("n_chains_total", C.c_int64)]
 
 
 class PeakStats(C.Structure):
@@ -59,7 +61,8 @@ class PeakStats(C.Structure):
                 ("proposals", C.c_uint64), ("evaluated", C.c_uint64), ("accepted", C.c_uint64),
                 ("accepted_moves", C.c_uint64), ("sweeps", C.c_uint64), ("columns_gathered", C.c_uint64),
                 ("last_stage_ms", C.c_double), ("last_kernel_ms", C.c_double),
-                ("last_kernel_launches", C.c_int64)]
+                ("last_kernel_launches", C.c_int64),
+                ("chi2_min_mean", C.c_double), ("n_chains_total", C.c_int64)]
 
 
 class EdgeConfig(C.Structure):
@@ -78,8 +81,11 @@ class EdgeResults(C.Structure):
                 ("chi2", C.c_double), ("chi2_min", C.c_double),
                 ("sweeps", C.c_uint64), ("proposals", C.c_uint64), ("evaluated", C.c_uint64),
                 ("accepted", C.c_uint64), ("lookups", C.c_uint64), ("violations", C.c_uint64),
-                ("last_stage_ms", C.c_double)]
+                ("last_stage_ms", C.c_double),
+                ("chi2_min_mean", C.c_double), ("n_chains_total", C.c_int64)]
 
+
+COMM_ID_BYTES = 128     # SAC_COMM_ID_BYTES
 
 KERNEL_TYPES = {"finiteT": 0, "zeroT": 1, "bosonic": 2}
 
@@ -154,6 +160,15 @@ def load_library():
     L.sac_get_chains_per_wave.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sac_set_proposals_per_step.argtypes = [vp, C.c_int32]
     L.sac_get_proposals_per_step.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.sac_get_gbar_mean.argtypes = [vp, dp]
+    L.sac_edge_get_gbar_mean.argtypes = [vp, dp]
+    L.sac_edge_get_move_means.argtypes = [vp, dp, dp, dp]
+    i32p = C.POINTER(C.c_int32)
+    L.sac_comm_unique_id.argtypes = [vp]
+    L.sac_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.sac_comm_info.argtypes = [vp, i32p, i32p, ip, ip]
+    L.sac_edge_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.sac_edge_comm_info.argtypes = [vp, i32p, i32p, ip, ip]
     L.sac_edge_build_tables.argtypes = [vp, C.c_int32, C.POINTER(TableSpec), dp, dp]
     L.sac_edge_upload_data.argtypes = [vp, dp, dp]
     L.sac_edge_get_tables.argtypes = [vp, C.c_int32, dp, dp, dp]
@@ -178,6 +193,22 @@ def load_library():
             getattr(L, name).restype = C.c_int
     _LIB = L
     return L
+
+
+def comm_unique_id():
+    """sac_comm_unique_id (ncclGetUniqueId): 128 bytes rank 0 hands to the other ranks."""
+    L = load_library()
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = L.sac_comm_unique_id(buf)
+    if rc != 0:
+        raise SacError(f"libsac_hip error {rc}: {L.sac_last_error().decode()}")
+    return buf.raw
+
+
+def _comm_info(fn, h, check):
+    r, w, m, a = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+    check(fn(h, C.byref(r), C.byref(w), C.byref(m), C.byref(a)))
+    return dict(rank=r.value, world=w.value, merges=m.value, allreduce_calls=a.value)
 
 
 def _dp(a):
@@ -207,6 +238,7 @@ class SacHandle:
         self.n_state = 2 * (n_omega + n_peak) if kind == KIND_PEAK else n_omega
         self.n_windows = 11 if kind == KIND_PEAK else 4
         self.n_rates = 11 if kind == KIND_PEAK else 6
+        self.merged_over_ranks = False
 
     def _check(self, rc):
         if rc != 0:
@@ -258,6 +290,12 @@ class SacHandle:
         self._check(self.L.sac_get_gbar(self.h, chain, _dp(g), C.byref(c), C.byref(m)))
         return g, c.value, m.value
 
+    def gbar_mean(self):
+        """Gbar averaged over the chains (all ranks' after a merged sample stage), eigenbasis, n_tau entries."""
+        g = np.empty(self.n_tau)
+        self._check(self.L.sac_get_gbar_mean(self.h, _dp(g)))
+        return g
+
     def set_gbar(self, gbar, chi2, chi2_min, chain=-1):
         gbar = np.ascontiguousarray(gbar, dtype=np.float64)
         self._check(self.L.sac_set_gbar(self.h, chain, _dp(gbar), chi2, chi2_min))
@@ -282,6 +320,17 @@ class SacHandle:
         out = C.c_int32(0)
         self._check(self.L.sac_get_proposals_per_step(self.h, C.byref(out)))
         return out.value
+
+    def comm_init(self, unique_id, rank, world):
+        """sac_comm_init: from here on every stage call ends with the merge over ranks (one fused all-reduce(sum) + one
+        all-reduce(min) on the handle's stream) and the reduced getters answer for all ranks' chains."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise SacError(f"unique id has {len(unique_id)} bytes, expected {COMM_ID_BYTES}")
+        self._check(self.L.sac_comm_init(self.h, C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES), int(rank), int(world)))
+        self.merged_over_ranks = True
+
+    def comm_info(self):
+        return _comm_info(self.L.sac_comm_info, self.h, self._check)
 
     def adjust_windows(self, steps, theta):
         self._check(self.L.sac_adjust_windows(self.h, int(steps), float(theta)))
@@ -433,6 +482,17 @@ class SacEdgeHandle:
         self.h = C.c_void_p()
         self._check(self.L.sac_edge_create(C.byref(self.cfg), C.byref(self.h)))
         self._keep = None
+        self.merged_over_ranks = False
+
+    def comm_init(self, unique_id, rank, world):
+        """sac_edge_comm_init: see SacHandle.comm_init."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise SacError(f"unique id has {len(unique_id)} bytes, expected {COMM_ID_BYTES}")
+        self._check(self.L.sac_edge_comm_init(self.h, C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES), int(rank), int(world)))
+        self.merged_over_ranks = True
+
+    def comm_info(self):
+        return _comm_info(self.L.sac_edge_comm_info, self.h, self._check)
 
     def _check(self, rc):
         if rc != 0:
@@ -518,6 +578,7 @@ class SacEdgeHandle:
         return dict(chi2_res=np.array(r.chi2_res[:]), edge_res=f(r.edge_res), n0_res=f(r.n0_res), wn0_res=f(r.wn0_res),
                     amp_ar=f(r.amp_accept_rates), n0=np.array(r.n0[:]), eps0=np.array(r.eps0[:]),
                     dn0=np.array(r.dn0[:]), deps0=np.array(r.deps0[:]), chi2=r.chi2, chi2_min=r.chi2_min,
+                    chi2_min_mean=r.chi2_min_mean, n_chains_total=r.n_chains_total,
                     sweeps=r.sweeps, proposals=r.proposals, evaluated=r.evaluated, accepted=r.accepted,
                     lookups=r.lookups, violations=r.violations, last_stage_ms=r.last_stage_ms)
 
@@ -537,11 +598,25 @@ class SacEdgeHandle:
         self._check(self.L.sac_edge_get_avg(self.h, chain, _dp(w), _dp(A)))
         return w.reshape(2, n1).T.copy(), A.reshape(2, n1).T.copy()
 
+    def move_means(self):
+        """Chain means (all ranks' after a merged stage) of the per-delta windows and cluster sizes, [N_w+1, 2] each, and
+        (lowest, highest) continuum frequency of side 1: what write_res prints (edge:1454-1506)."""
+        n1 = self.n_omega + 1
+        dw, nm, ext = np.empty(2 * n1), np.empty(2 * n1), np.empty(2)
+        self._check(self.L.sac_edge_get_move_means(self.h, _dp(dw), _dp(nm), _dp(ext)))
+        return dw.reshape(2, n1).T.copy(), nm.reshape(2, n1).T.copy(), ext
+
     def get_gbar(self, chain=0):
         g = np.empty(self.n_tau)
         c, m = C.c_double(), C.c_double()
         self._check(self.L.sac_edge_get_gbar(self.h, chain, _dp(g), C.byref(c), C.byref(m)))
         return g, c.value, m.value
+
+    def gbar_mean(self):
+        """Gbar averaged over the chains (all ranks' after a merged stage), eigenbasis, n_tau entries."""
+        g = np.empty(self.n_tau)
+        self._check(self.L.sac_edge_get_gbar_mean(self.h, _dp(g)))
+        return g
 
     def validation_chi2(self, cov_this, td_other, gbar_mean=None, per_chain=False):
         """calc_cv.jl:29-58 on the device: chi2_v (not divided by N_tau) of the chain-mean Gbar (or of gbar_mean) against the

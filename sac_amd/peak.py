@@ -136,7 +136,10 @@ class PeakSAC:
 
     def __init__(self, N_omega, N_p, A_0, omega_m, d_omega, d_omega_h, theta_0, f_anneal, a_criterion,
                  N_anneal, anneal_steps, sample_steps, G_file, output_folder, fix_edge, symm, kernel_type,
-                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None):
+                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None, chi2_min_mode="chain_mean"):
+        if chi2_min_mode not in ("chain_mean", "min"):
+            raise ValueError("chi2_min_mode must be 'chain_mean' or 'min'")
+        self.chi2_min_mode = chi2_min_mode      # see FreeSAC: the single-chain equivalent of the reference's chi2_min, or the minimum
         self.comm = comm
         self.is_root = comm is None or comm.rank == 0
         self.N_omega, self.N_p, self.A_0 = int(N_omega), int(N_p), float(A_0)
@@ -230,23 +233,31 @@ class PeakSAC:
         offset = 0 if self.comm is None else self.comm.rank * self.n_chains
         self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device, chain_offset=offset)
         self.h.set_indiv_update(self.indiv_update)
+        if self.comm is not None:
+            self.comm.attach(self.h)                                # RCCL groups: the merge goes behind the C ABI
         self._merge()
 
     def _merge(self):
-        st = self.h.peak_stats()
+        st = self.h.peak_stats()                                    # over all ranks already when the handle merges
         self.sampled_chi2, self.chi2_min = st.sampled_chi2, st.chi2_min
+        cmm = st.chi2_min_mean
         self.accept_rates = np.array(st.accept_rates[:])
         self.update_windows = np.array(st.windows[:])
         self.edge_res = np.array([list(r) for r in st.edge_res])
         self.bounds = np.array(st.bounds[:])
         self.weights = np.array(st.weights[:])
-        if self.comm is not None:                                   # one all-reduce per stage
+        if self.comm is not None and not self.h.merged_over_ranks:  # host-side groups: one all-reduce per stage
             m = self.comm.merge_named(self.n_chains, dict(sampled_chi2=self.sampled_chi2, accept_rates=self.accept_rates,
                                                           update_windows=self.update_windows, edge_res=self.edge_res,
-                                                          bounds=self.bounds, weights=self.weights),
+                                                          bounds=self.bounds, weights=self.weights, chi2_min_mean=cmm),
                                       mins=dict(chi2_min=self.chi2_min))
             for k in ("sampled_chi2", "chi2_min", "accept_rates", "update_windows", "edge_res", "bounds", "weights"):
                 setattr(self, k, m[k])
+            cmm = m["chi2_min_mean"]
+        # the schedule criteria (peak:1343, 1386, 1545) see ONE chain's minimum in the reference: chain mean by default
+        self.chi2_min_all = self.chi2_min
+        if self.chi2_min_mode == "chain_mean":
+            self.chi2_min = cmm
         return st
 
     def repair_chains(self):
@@ -370,7 +381,7 @@ class PeakSAC:
         p = self.prob
         div = getattr(self, "spec_divisor", 1.0) if self.h is not None else 1.0
         hists = [self.h.histogram_peak(w) / (div if self._binned() else 1.0) for w in range(4)]
-        if self.comm is not None:
+        if self.comm is not None and not self.h.merged_over_ranks:
             m = self.comm.merge_named(self.n_chains, {str(w): hists[w] for w in range(4)})
             hists = [m[str(w)] for w in range(4)]
         if not self.is_root:
@@ -446,7 +457,7 @@ class PeakSAC:
         self.write_log("Initialization Finished.")
         self.write_log("Beginning Initial Sampling.")
         self.intial_sampling(theta)
-        if self.chi2_min > 1000 * self.td.n_tau:                    # peak:1522-1533
+        if self.chi2_min_all > 1000 * self.td.n_tau:                # peak:1522-1533 (no chain at all found a start)
             self.indiv_update = True
             self.initialize()
             self.intial_sampling(theta)

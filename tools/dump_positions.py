@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Writes the delta positions and tuned single-move windows of every chain of a tuned run at the bench shape (BASELINE
 configs[1]) for `tools/gather_probe --positions`: int32 header (chains, n_omega, n_grid, 0), uint32 positions
-[chains][n_omega] (relative grid index = table row), float64 window[chains]."""
+[chains][n_omega] (relative grid index = table row), float64 window[chains].
+    dump_positions.py [out] [chains] [d_omega]      d_omega 1e-4 (48.8 MiB table, default), 1e-5 (488 MiB), 2.5e-6 (1953 MiB)"""
 import os
 import sys
 
@@ -13,8 +14,9 @@ from sac_amd.synth import synthetic_timedata  # noqa: E402
 
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/positions.bin"
 chains = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+d_omega = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-4
 td = synthetic_timedata(n_tau=64, seed=12345)
-prob = FreeProblem(td, 2000, 0.0, 10.0, 1e-4, par=1, kernel_type="bosonic")
+prob = FreeProblem(td, 2000, 0.0, 10.0, d_omega, par=1, kernel_type="bosonic")
 h = prob.make_handle(n_chains=chains, seed=12345, device_tables=True)
 h.adjust_windows(1000, 1.0)
 pos = np.empty((chains, 2000), dtype=np.uint32)

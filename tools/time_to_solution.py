@@ -5,7 +5,8 @@
   python tools/time_to_solution.py free [chains] [spread]   sac/free/out_files/bosonic_delta_peak   (tests/golden/free_bdp)
   python tools/time_to_solution.py edge [chains] [spread]   sac/edge/out_files/hchain_beta2048_single/...  (tests/golden/edge/hchain_single)
 
-The reference's FULL schedule is run (same Theta ladder, same sweeps per stage, same stop rules).  One JSON line."""
+The reference's FULL schedule is run (same Theta ladder, same sweeps per stage, same stop rules).  One JSON line.
+SAC_CHI2_MIN_MODE=chain_mean|min selects how the many-chain run forms the chi2_min of the Theta criteria (default chain_mean)."""
 import json
 import os
 import sys
@@ -19,6 +20,7 @@ G = os.path.join(ROOT, "tests", "golden")
 what = sys.argv[1]
 chains = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 spread = len(sys.argv) > 3 and sys.argv[3] == "spread"
+mode = os.environ.get("SAC_CHI2_MIN_MODE", "chain_mean")
 t_all = time.time()
 phases = {}
 
@@ -33,7 +35,7 @@ def timed(name, fn):
 if what == "free":
     from sac_amd.free import FreeSAC
     REF = f"{G}/free_bdp"
-    s = FreeSAC.from_infile(f"{REF}/in_free.in", n_chains=chains, seed=7, spread_sampling=spread, device_tables=True)
+    s = FreeSAC.from_infile(f"{REF}/in_free.in", n_chains=chains, seed=7, spread_sampling=spread, device_tables=True, chi2_min_mode=mode)
     s.G_file, s.output_folder = f"{REF}/t.in", "/tmp/tts_free"
     per = []
     s.init_outfiles()
@@ -52,7 +54,7 @@ if what == "free":
     z = (v.mean(axis=1) - ref[:n, 3]) / (v.std(axis=1, ddof=1) * np.sqrt(1 + 1 / v.shape[1]))
     ref_row = np.loadtxt(f"{REF}/sample.csv", delimiter=",", skiprows=1, ndmin=2)[0]
     got_row = np.loadtxt(s.sample_file, delimiter=",", skiprows=1, ndmin=2)[0]
-    out = {"run": "sac/free bosonic_delta_peak, full reference schedule", "chains": chains, "spread_sampling": spread,
+    out = {"run": "sac/free bosonic_delta_peak, full reference schedule", "chains": chains, "spread_sampling": spread, "chi2_min_mode": mode,
            "gpu_seconds": phases, "gpu_total_s": round(time.time() - t_all, 1),
            "reference_log_seconds": {"equilibration": 1.68, "main_anneal": 24.27, "final_anneal": 14.16, "note": "one chain, unknown CPU"},
            "anneal_points": [len(got), len(ref)], "z_max": float(np.abs(z).max()), "z_rms": float(np.sqrt((z ** 2).mean())),
@@ -61,7 +63,7 @@ if what == "free":
 elif what == "edge":
     from sac_amd.edge import EdgeSAC
     REF = f"{G}/edge/hchain_single"
-    s = EdgeSAC.from_infile(f"{REF}/in_edge.in", n_chains=chains, seed=3, spread_sampling=spread)
+    s = EdgeSAC.from_infile(f"{REF}/in_edge.in", n_chains=chains, seed=3, spread_sampling=spread, chi2_min_mode=mode)
     s.G_file, s.output_folder = f"{REF}/t.in", "/tmp/tts_edge"
     if len(sys.argv) > 4:
         s.d_omega = float(sys.argv[4])
@@ -97,7 +99,7 @@ elif what == "edge":
     # the reference prints is the scatter of its bins, far below the run-to-run scatter of the slow edge mode)
     rs = np.genfromtxt(f"{REF}/sample.csv", delimiter=",", skip_header=1)
     gs = np.genfromtxt(os.path.join(s.output_folder, "sample.csv"), delimiter=",", skip_header=1)
-    out = {"run": "sac/edge hchain_beta2048_single, full reference schedule", "chains": chains, "spread_sampling": spread,
+    out = {"run": "sac/edge hchain_beta2048_single, full reference schedule", "chains": chains, "spread_sampling": spread, "chi2_min_mode": mode,
            "d_omega": s.d_omega, "gpu_seconds": phases, "gpu_total_s": round(time.time() - t_all, 1),
            "reference_log_seconds": {"initialization": 3.7, "equilibration": 5.32, "main_anneal": 32.88, "final_anneal": 24.95,
                                      "final_sampling": 5.37, "note": "one chain, unknown CPU"},
