@@ -179,11 +179,12 @@ typedef struct {
 /* which = 0: K_array (free) / Kp_array (peak); 1: Kn_array (peak).  tau[n_tau]; U[n_tau][n_tau] row-major = the
  * reference's `cov` (eigenvectors in columns, free:107-108). */
 int sac_build_table(sac_handle_t *h, int32_t which, const sac_table_spec_t *spec, const double *tau, const double *U);
-/* No counterpart in the reference.  sac_build_table for callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc): same arguments, same table bit for bit, but
- * tau and U are staged in a file-scope device array of the library (132 KB per GPU, held until the process ends)
- * instead of two hipMalloc'ed buffers; the call makes no hipMalloc / hipFree.  Limit: n_tau <= SAC_MAX_N_TAU
- * (SAC_E_INVALID beyond).  The array is shared by all handles on a GPU: calls that overlap on one GPU race. */
+/* No counterpart in the reference.  sac_build_table for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc): same arguments, same table bit for bit, but tau and U are staged in a file-scope
+ * device array of the library (132 KB per GPU, held until the process ends) instead of two hipMalloc'ed buffers; the
+ * call makes no hipMalloc / hipFree.  It does use blocking copies and stream synchronisation, so it is NOT for code
+ * under HIP graph capture.  Limit: n_tau <= SAC_MAX_N_TAU (SAC_E_INVALID beyond).  The array is shared by all handles
+ * on a GPU; calls from several host threads of one process take turns (a per-GPU lock spans copy-in to kernel end). */
 int sac_build_table_noalloc(sac_handle_t *h, int32_t which, const sac_table_spec_t *spec, const double *tau, const double *U);
 /* out[n_grid][n_tau], tau contiguous: the table as the device holds it (uploaded or built). */
 int sac_get_table(sac_handle_t *h, int32_t which, double *out);

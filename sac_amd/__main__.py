@@ -69,7 +69,7 @@ def main(argv=None):
         if len(a.args) < 5:
             ap.error("scan needs: edge|peak AXIS V_0 DELTA N [fixed values]")
         prog, axis = a.args[0], a.args[1]
-        values = scan_values(float(a.args[2]), float(a.args[3]), int(a.args[4]))
+        values = scan_values(a.args[2], a.args[3], int(a.args[4]))        # the argument strings: exact decimals, as bc has them
         rest = [float(x) for x in a.args[5:]]
         names = ("A_c", "A_r", "p") if prog == "edge" else ("N_p",)
         fixed = {n: v for n, v in zip(names, rest) if n != axis}
@@ -78,7 +78,9 @@ def main(argv=None):
             import torch
             import torch.distributed as dist
             torch.cuda.set_device(kw["device"])
-            dist.init_process_group(a.backend if a.backend != "nccl" else "nccl",
+            from .cross_val import GATHER_TIMEOUT
+            # scan points are whole runs (minutes each) dealt round-robin: the ranks reach the final gather far apart
+            dist.init_process_group(a.backend, timeout=GATHER_TIMEOUT,
                                     **({"device_id": torch.device("cuda", kw["device"])} if a.backend == "nccl" else {}))
         results = run_scan_partition(units, rank, world, **kw)
         if rank == 0:
@@ -97,7 +99,8 @@ def main(argv=None):
             import torch
             import torch.distributed as dist
             torch.cuda.set_device(kw["device"])
-            dist.init_process_group("nccl", device_id=torch.device("cuda", kw["device"]))
+            from .cross_val import GATHER_TIMEOUT
+            dist.init_process_group("nccl", timeout=GATHER_TIMEOUT, device_id=torch.device("cuda", kw["device"]))
         if len(a.args) < 2:
             ap.error("cv-all needs: REP_FIRST REP_LAST [free,peak,edge]")
         params = tuple(a.args[2].split(",")) if len(a.args) > 2 else ("free", "peak", "edge")

@@ -217,22 +217,37 @@ def partition_units(units, rank, world):
     return list(units[rank::world])
 
 
+# Units are whole runs (an edge run takes minutes) dealt round-robin, so the ranks reach the final gather far apart: it
+# must not sit under a collective watchdog sized for per-stage all-reduces (NCCL's default is 10 minutes).
+import datetime
+GATHER_TIMEOUT = datetime.timedelta(hours=48)
+_gather_group = None
+
+
+def gather_objects(obj, world):
+    """Every rank's `obj` on every rank, through a host-side (gloo) group of its own with GATHER_TIMEOUT -- whatever
+    backend and timeout the default group has.  Collective; the group is created on first use."""
+    global _gather_group
+    import torch.distributed as dist
+    if _gather_group is None:
+        _gather_group = dist.new_group(backend="gloo", timeout=GATHER_TIMEOUT)
+    out = [None] * world
+    dist.all_gather_object(out, obj, group=_gather_group)
+    return out
+
+
 def run_partition(units, rank, world, runner, gather=None, **kw):
     """Deals `units` round-robin to the ranks, runs this rank's share with runner(unit, **kw) and returns, on every
-    rank, {unit: result} for all units.  gather(obj) -> list of every rank's obj (default:
-    torch.distributed.all_gather_object when world > 1).  Shared by the cross-validation units and the scans (scan.py)."""
+    rank, {unit: result} for all units.  gather(obj) -> list of every rank's obj (default: gather_objects, a gloo
+    all_gather_object with a long timeout, when world > 1).  Shared by the cross-validation units and the scans (scan.py)."""
     mine = {}
     for unit in partition_units(units, rank, world):
         mine[unit] = runner(unit, **kw)
     if world == 1:
         return mine
     if gather is None:
-        import torch.distributed as dist
-
         def gather(obj):
-            out = [None] * world
-            dist.all_gather_object(out, obj)
-            return out
+            return gather_objects(obj, world)
     merged = {}
     for part in gather(mine):
         merged.update(part)

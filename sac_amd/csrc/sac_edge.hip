@@ -15,6 +15,7 @@
 #include "table_build.h"
 #include "cv_score.h"
 #include "comm.h"
+#include "devbuf.h"
 
 using namespace sacdev;
 
@@ -1316,13 +1317,18 @@ extern "C" int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const
     int rc;
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    DevBuf b_dP, b_dC, b_dAcc, b_dW;      // released on every exit path
     EdgeReplayProp *dP = nullptr;
     double *dW = nullptr, *dC = nullptr;
     int *dAcc = nullptr;
-    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * sizeof(EdgeReplayProp)));
-    HIP_TRY(hipMalloc((void **)&dW, (size_t)n_w * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dC, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dAcc, (size_t)n * sizeof(int)));
+    HIP_TRY(b_dP.alloc((size_t)n * sizeof(EdgeReplayProp)));
+    dP = b_dP.as<std::remove_pointer_t<decltype(dP)>>();
+    HIP_TRY(b_dW.alloc((size_t)n_w * sizeof(double)));
+    dW = b_dW.as<std::remove_pointer_t<decltype(dW)>>();
+    HIP_TRY(b_dC.alloc((size_t)n * sizeof(double)));
+    dC = b_dC.as<std::remove_pointer_t<decltype(dC)>>();
+    HIP_TRY(b_dAcc.alloc((size_t)n * sizeof(int)));
+    dAcc = b_dAcc.as<std::remove_pointer_t<decltype(dAcc)>>();
     HIP_TRY(hipMemcpy(dP, props, (size_t)n * sizeof(EdgeReplayProp), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dW, w_new, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice));
     EdgeParams p;
@@ -1334,10 +1340,6 @@ extern "C" int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(dP));
-    HIP_TRY(hipFree(dW));
-    HIP_TRY(hipFree(dC));
-    HIP_TRY(hipFree(dAcc));
     return SAC_OK;
 }
 

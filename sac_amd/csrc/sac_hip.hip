@@ -22,6 +22,7 @@
 #include "table_build.h"
 #include "cv_score.h"
 #include "comm.h"
+#include "devbuf.h"
 
 using namespace sacdev;
 
@@ -764,6 +765,7 @@ static __device__ __align__(256) double scratch[SCRATCH_DOUBLES];
 constexpr int MAX_DEVICES = 64;
 static std::mutex g_scratch_mutex;
 static double *g_scratch_ptr[MAX_DEVICES] = {};
+static std::mutex g_scratch_use[MAX_DEVICES];   // one user of a GPU's scratch array at a time (all handles on it share the array)
 
 // The calling thread's current device must be `device`.
 static int resolve_scratch(int device, double **out)
@@ -1061,6 +1063,9 @@ extern "C" int sac_build_table_noalloc(sac_handle_t *h, int32_t which, const sac
         if (!std::isfinite(tau[j])) return fail(SAC_E_INVALID, "sac_build_table_noalloc: non-finite tau[%zu]", j);
     double *d_tau = h->scratch, *d_U = h->scratch + SAC_MAX_N_TAU;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // held from the first copy into the array to the end of the kernel that reads it: two host threads building tables
+    // on one GPU (through any handles) take turns instead of overwriting each other's tau / U
+    std::lock_guard<std::mutex> scratch_user(g_scratch_use[h->cfg.device]);
     HIP_TRY(hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice));
     TableSpec sp;
@@ -1380,6 +1385,7 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
         const int cpw = ua ? packed_chains_per_wave(h) : 1;
         h->last_chains_per_wave = cpw;
         if (cpw > 1) {
+            h->last_proposals_per_step = 1;      // a packed handle does not speculate
             // several chains per wave (free_sweep_packed.h): same chains, other mapping onto the wave
             const int lpc = 64 / cpw;
             const int T = (lpc >= h->cfg.n_tau) ? 1 : (2 * lpc >= h->cfg.n_tau) ? 2 : 4;
@@ -2038,12 +2044,16 @@ extern "C" int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sa
                 if (q.k[e] == q.k[f]) return fail(SAC_E_INVALID, "sac_replay: proposal %lld repeats delta %d", (long long)i, q.k[e]);
     }
     if (n == 0) return stage_end(h, 0, 0);
+    DevBuf b_dP, b_dC, b_dAcc, b_dW;      // released on every exit path
     ReplayProp *dP = nullptr;
     double *dC = nullptr;
     int *dAcc = nullptr;
-    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * sizeof(ReplayProp)));
-    HIP_TRY(hipMalloc((void **)&dC, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dAcc, (size_t)n * sizeof(int)));
+    HIP_TRY(b_dP.alloc((size_t)n * sizeof(ReplayProp)));
+    dP = b_dP.as<std::remove_pointer_t<decltype(dP)>>();
+    HIP_TRY(b_dC.alloc((size_t)n * sizeof(double)));
+    dC = b_dC.as<std::remove_pointer_t<decltype(dC)>>();
+    HIP_TRY(b_dAcc.alloc((size_t)n * sizeof(int)));
+    dAcc = b_dAcc.as<std::remove_pointer_t<decltype(dAcc)>>();
     HIP_TRY(hipMemcpy(dP, rel.data(), (size_t)n * sizeof(ReplayProp), hipMemcpyHostToDevice));
     FreeParams p;
     fill_params(h, p);
@@ -2054,9 +2064,6 @@ extern "C" int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sa
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(dP));
-    HIP_TRY(hipFree(dC));
-    HIP_TRY(hipFree(dAcc));
     return stage_end(h, 0, 0);
 }
 
@@ -2090,12 +2097,16 @@ extern "C" int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, con
         }
     }
     if (n == 0) return stage_end(h, 0, 0);
+    DevBuf b_dP, b_dC, b_dAcc, b_dW;      // released on every exit path
     PeakReplayProp *dP = nullptr;
     double *dC = nullptr;
     int *dAcc = nullptr;
-    HIP_TRY(hipMalloc((void **)&dP, (size_t)n * sizeof(PeakReplayProp)));
-    HIP_TRY(hipMalloc((void **)&dC, (size_t)n * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&dAcc, (size_t)n * sizeof(int)));
+    HIP_TRY(b_dP.alloc((size_t)n * sizeof(PeakReplayProp)));
+    dP = b_dP.as<std::remove_pointer_t<decltype(dP)>>();
+    HIP_TRY(b_dC.alloc((size_t)n * sizeof(double)));
+    dC = b_dC.as<std::remove_pointer_t<decltype(dC)>>();
+    HIP_TRY(b_dAcc.alloc((size_t)n * sizeof(int)));
+    dAcc = b_dAcc.as<std::remove_pointer_t<decltype(dAcc)>>();
     HIP_TRY(hipMemcpy(dP, props, (size_t)n * sizeof(PeakReplayProp), hipMemcpyHostToDevice));
     PeakParams pp;
     fill_peak_params(h, pp);
@@ -2106,9 +2117,6 @@ extern "C" int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, con
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(dP));
-    HIP_TRY(hipFree(dC));
-    HIP_TRY(hipFree(dAcc));
     return stage_end(h, 0, 0);
 }
 

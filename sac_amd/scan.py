@@ -23,8 +23,12 @@ SCAN_AXES = {"edge": ("A_c", "A_r", "p"), "peak": ("A_0",)}
 
 
 def scan_values(v_0, delta, n):
-    """qsub_*_scan.sh: v_0 + delta * (task - 1), task = 1..n (bc scale=2: two decimals)."""
-    return [round(v_0 + delta * i, 2) for i in range(int(n))]
+    """qsub_*_scan.sh: v_0 + delta * (task - 1), task = 1..n, as `bc` with scale=2 evaluates it: + and * keep the operands'
+    own scale (p_0 = 0.5, delta = 0.025 gives .525, not 0.52), so the values are formed in exact decimal arithmetic from
+    the argument STRINGS and carry max(scale of v_0, scale of delta) decimals.  Floats are taken by their shortest repr."""
+    from decimal import Decimal
+    a, d = Decimal(str(v_0)), Decimal(str(delta))
+    return [float(a + d * i) for i in range(int(n))]
 
 
 def scan_units(program, axis, values, **fixed):
@@ -116,12 +120,10 @@ def sharded_theta_scan(s, theta_1, theta_2, rank=0, world=1, pass_fraction=0.1, 
     if world == 1:
         return mine
     if gather is None:
-        import torch.distributed as dist
+        from .cross_val import gather_objects
 
         def gather(obj):
-            out = [None] * world
-            dist.all_gather_object(out, obj)
-            return out
+            return gather_objects(obj, world)     # gloo group with a long timeout: the ranks' points differ in length
     merged = {}
     for part in gather(mine):
         merged.update(part)

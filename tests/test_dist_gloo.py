@@ -187,6 +187,49 @@ def test_scan_points_round_robin_over_two_ranks():
     assert r0["n"] == r1["n"] == 5 and r0["best"] == r1["best"] == 0.4         # every rank learns every point
 
 
+def _late_worker(rank, world, port, out):
+    import datetime
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # the default group's collectives give up after 2 s; the partition's gather must not depend on that
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=2))
+    from sac_amd.scan import run_scan_partition, scan_units, scan_values
+
+    def runner(unit, **kw):
+        if rank == 1:
+            time.sleep(6.0)          # this rank's point takes far longer than the default group's timeout
+        return dict(chi2_avg=1.0 + rank, rank=rank)
+
+    units = scan_units("edge", "p", scan_values("0.5", "0.025", 2), A_c=0.0, A_r=0.5)
+    t0 = time.time()
+    res = run_scan_partition(units, rank, world, runner=runner)
+    out[rank] = dict(n=len(res), ranks=sorted(r["rank"] for r in res.values()), waited=time.time() - t0)
+    dist.destroy_process_group()
+
+
+def test_partition_gather_survives_a_rank_that_finishes_late():
+    """Scan points / cross-validation units are whole runs dealt round-robin; the early ranks wait in the final gather for
+    the slow one far longer than a collective watchdog allows.  The gather runs on its own gloo group with a long timeout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_late_worker, args=(2, port, out), nprocs=2, join=True)
+    assert out[0]["n"] == out[1]["n"] == 2 and out[0]["ranks"] == out[1]["ranks"] == [0, 1]
+    assert out[0]["waited"] > 4.0                                              # rank 0 really sat in the gather
+
+
+def test_scan_values_keep_the_operands_decimals():
+    """qsub_p_scan.sh: `bc` keeps the operands' scale for + and *: p_0 = 0.5, delta = 0.025 gives .525 (not 0.52), and the
+    output folders p_%.3f follow."""
+    from sac_amd.scan import scan_values
+    assert scan_values("0.5", "0.025", 4) == [0.5, 0.525, 0.55, 0.575]
+    assert scan_values(0.5, 0.025, 4) == [0.5, 0.525, 0.55, 0.575]
+    assert scan_values("0.3", "0.1", 5) == [0.3, 0.4, 0.5, 0.6, 0.7]           # no binary drift (0.30000000000000004)
+    assert ["%.3f" % v for v in scan_values("0.5", "0.025", 2)] == ["0.500", "0.525"]
+
+
 def test_theta_scan_points_follow_the_reference_ladder():
     from sac_amd.scan import scan_units, theta_scan_points
     pts = theta_scan_points(1.0, 0.1)                                          # edge:1805-1809, f_scan = 1.15

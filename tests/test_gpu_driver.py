@@ -51,8 +51,11 @@ def test_anneal_curve_follows_reference_run(tmp_path):
     print("z", np.round(z, 2))
     assert np.abs(z).max() < 4.0, z
     assert (z ** 2).mean() < 2.0 and abs(z.mean()) < 0.6, ((z ** 2).mean(), z.mean())
-    # chi2_min of 64 chains is a minimum over more samples: never far above the single chain's
-    assert (got[10:, 2] < ref[10:n, 2] * 1.05).all()
+    # anneal.csv's chi2_min column is the single-chain equivalent (mean over chains of each chain's own minimum,
+    # chi2_min_mode="chain_mean"): it tracks the reference's ONE chain instead of sinking with the number of chains
+    # (the reference's own column jitters by a few per cent from Theta to Theta), and the minimum over all chains lies below it
+    assert np.abs(np.log(got[10:, 2] / ref[10:n, 2])).max() < 0.12
+    assert s.chi2_min_all <= s.chi2_min
     # outputs exist in the reference's layout
     sw = open(os.path.join(s.output_folder, "sw000.csv")).read().split("\n")
     assert sw[0] == "omega,S" and len(sw) > 20

@@ -126,5 +126,8 @@ def test_peak_anneal_reference_schedule_z_test(tmp_path):
     assert (z ** 2).mean() < 2.0 and abs(z.mean()) < 0.6, ((z ** 2).mean(), z.mean())
     # fixed edge: the peak stays where initialize! put it, the weights are the input's (reference columns 5-10)
     np.testing.assert_allclose(got[:, 4:10], ref[:n_pts, 4:10], atol=1e-4)
-    # chi2_min of 64 chains lies at or below the single chain's (both approach the same minimum)
-    assert (got[15:, 2] <= ref[15:n_pts, 2] + 2e-3).all()
+    # the chi2_min column is the single-chain equivalent (mean over the chains of each chain's own minimum): it tracks the
+    # reference's ONE chain; the minimum over all 64 chains lies below it
+    print("chi2_min ratio", np.round(got[15:, 2] / ref[15:n_pts, 2], 3))
+    assert np.abs(np.log(got[15:, 2] / ref[15:n_pts, 2])).max() < 0.12
+    assert s.chi2_min_all <= s.chi2_min

@@ -56,3 +56,21 @@ def test_noalloc_argument_errors():
     h.build_table(0, "bosonic", td.tau, td.beta, td.cov, 0, 1e-3, noalloc=True)
     h.upload_data(td.G, td.sigma_inv)            # a table built this way completes a problem like any other
     h.close()
+
+
+def test_noalloc_call_leaves_free_device_memory_unchanged():
+    """The point of the entry: no device allocation.  hipMemGetInfo (through torch.cuda.mem_get_info) before and after a call
+    on a warmed-up handle (the first call may load code objects) must read the same number of free bytes, for the largest
+    supported N_tau; the allocating entry point is not required to (and is not checked)."""
+    import torch
+    big = synthetic_timedata(n_tau=128, seed=5, n_boot=500)
+    h = SacHandle(big.n_tau, 40, 4001, 0, 4000)
+    h.build_table(0, "bosonic", big.tau, big.beta, big.cov, 0, 2e-3, noalloc=True)      # warm-up
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(3):
+        h.build_table(0, "bosonic", big.tau, big.beta, big.cov, 0, 2e-3, noalloc=True)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 == free0, (free0, free1)
+    h.close()
