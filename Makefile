@@ -2,7 +2,11 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 HIPFLAGS ?= -O3 -std=c++20 --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fPIC -Wall -Wno-unused-value
 SRC = sac_amd/csrc/sac_hip.hip sac_amd/csrc/sac_edge.hip
-HDR = $(wildcard sac_amd/csrc/*.h) include/sac_hip.h
+HDR = $(sort $(wildcard sac_amd/csrc/*.h)) include/sac_hip.h
+# fingerprint of the sources a library was built from (sac_build_id()): ties rocprofv3 counter files (profiles/traffic.json)
+# to the binary they were measured on
+BUILD_ID := $(shell cat $(SRC) $(HDR) | sha256sum | cut -c1-16)
+HIPFLAGS += -DSAC_BUILD_ID=\"$(BUILD_ID)\"
 
 all: sac_amd/libsac_hip.so oracle
 

@@ -32,9 +32,14 @@ SWEEPS_PER_STEP = 400
 THETA = 1.0
 SEED = 12345
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-# measured gather-only ceiling for THIS workload's (cache-resident, concentrated) column distribution:
-# profiles/r02_gather_probe.txt, tools/gather_probe --positions on the positions of a tuned run at this shape
-GATHER_CEILING_GBS = 17368.0
+# measured gather-only ceilings (GB/s) on the SAMPLER'S OWN column distribution (tools/gather_probe --positions on the delta
+# positions and tuned windows of a run at this shape, 8 B per lane as the kernel loads, 4096 waves, 16 rows in flight; round 3:
+# profiles/r03_gather_probe.txt, which also holds the deliberately flat-support case and the 16 B/lane form): the roof of the
+# kernel's access pattern on that table, by table size.  The 48.8 MiB table is L2 / Infinity-Cache resident; of the 488 MiB
+# table at most 256 MB (52 %) can sit in the Infinity Cache, of the 1953 MiB table at most 13 %.
+GATHER_CEILING_GBS = 16467.5
+GATHER_CEILINGS_BY_GRID = {1000001: 9728.6, 4000001: 8133.9}
+GATHER_CEILING_SOURCE = "profiles/r03_gather_probe.txt"
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4           # peak engine clock
 # a wave64 VALU instruction occupies its SIMD for one "quad-cycle" (4 clocks: 16 lanes per clock); SQ_ACTIVE_INST_VALU
@@ -92,6 +97,21 @@ def cpu_baseline(prob, windows, wi, theta=THETA, seconds=10.0, procs=None):
             "per_core_value": tot["moves_per_s"] / procs}
 
 
+def load_traffic_json():
+    """profiles/traffic.json (rocprofv3 --pmc passes) if it was measured on the library that is running: (dict, None), else
+    (None, reason).  The file records sac_build_id() of the library under the profiler; a kernel edit without a new PMC
+    pass must not keep the old numerators."""
+    from sac_amd.lib import build_id
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError) as ex:
+        return None, f"profiles/traffic.json not readable ({ex})"
+    have, want = pmc.get("build_id"), build_id()
+    if have != want:
+        return None, f"profiles/traffic.json was measured on build {have}, this run uses build {want}: counter-based numbers withheld"
+    return pmc, None
+
+
 # ------------------------------------------------------------------------------------------------
 # HBM-resident regime, driver-timed in the same run (extra keys; the headline table is cache resident)
 # ------------------------------------------------------------------------------------------------
@@ -108,10 +128,8 @@ def hbm_regime(device, chains, theta=THETA):
     td = synthetic_timedata(n_tau=N_TAU, seed=SEED)
     out = []
 
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("hbm_regime", {})
-    except (OSError, ValueError):
-        pmc = {}
+    pmc_all, pmc_why = load_traffic_json()
+    pmc = {} if pmc_all is None else pmc_all.get("hbm_regime", {})
 
     def run(name, key, h, stats, sweeps, table_bytes, rebuild_cols=0):
         h.adjust_windows(200, theta)
@@ -130,25 +148,25 @@ def hbm_regime(device, chains, theta=THETA):
         e = {"workload": name, "bound": "hbm", "launches": nl, "avg_launch_ms": kms / nl, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "algorithmic_GBps": alg, "algorithmic_over_hbm_peak": alg / HBM_PEAK_GBS,
              "algorithmic_bytes_per_launch": cols * N_TAU * 8 / nl}
+        # `achieved` = the ALGORITHMIC gather rate (columns the proposals read x N_tau x 8 B over the HIP-event launch time of
+        # this run); `frac` = against the MEASURED gather-only ceiling of this access pattern on this table size
+        # (GATHER_CEILINGS_BY_GRID); the nominal 8 TB/s HBM peak is the second key.  The counter traffic beyond L2 rides
+        # along only when profiles/traffic.json was measured on the build that is running.
+        n_grid = table_bytes // 512
+        ceil = GATHER_CEILINGS_BY_GRID.get(n_grid)
+        e.update({"achieved": alg, "measured_gather_ceiling_GBps": ceil, "measured_gather_ceiling_source": GATHER_CEILING_SOURCE,
+                  "frac": None if ceil is None else alg / ceil, "frac_of_nominal_hbm_peak": alg / HBM_PEAK_GBS,
+                  "infinity_cache_share_upper_bound": min(1.0, 256e6 / table_bytes),
+                  "frac_note": "algorithmic rate over the gather-only ceiling measured on the free sampler's own column distribution on a "
+                               "table of this size (8 B per lane, 4096 waves); sac/peak entries use the same table sizes and that ceiling"})
         t = pmc.get(key)
         if t and sweeps == 100 and h.n_chains == 4096:
-            # bytes that crossed the fabric per 100-sweep launch (rocprofv3 --pmc on this launch shape, profiles/traffic.json)
-            # over the launch time measured here
-            ach = t["bytes_per_launch"] / (kms / nl / 1e3) / 1e9
-            e.update({"achieved": ach, "traffic": t["bytes_per_launch"],
-                      "achieved_note": "counter traffic beyond L2 per launch, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json, "
-                                       "over the HIP-event launch time of this run"})
+            cnt = t["bytes_per_launch"] / (kms / nl / 1e3) / 1e9
+            e.update({"traffic": t["bytes_per_launch"], "counter_GBps_beyond_L2": cnt,
+                      "traffic_note": "(2*FETCH_SIZE+WRITE_SIZE)*1024 per launch from profiles/traffic.json (same build), over the launch "
+                                      "time of this run; FETCH_SIZE includes Infinity-Cache hits"})
         else:
-            ach = alg
-            e.update({"achieved": alg, "traffic": None})
-        if table_bytes >= (1 << 30) and ach <= HBM_PEAK_GBS:
-            e["frac"] = ach / HBM_PEAK_GBS
-        else:
-            # a 488 MiB table is half resident in the 256 MB Infinity Cache, which sits beyond L2 and is faster than HBM:
-            # neither the algorithmic nor the counter rate is a fraction of the HBM roof there (both can exceed it)
-            e.update({"frac": None, "over_hbm_peak": ach / HBM_PEAK_GBS,
-                      "frac_note": "table partly resident in the 256 MB Infinity Cache: rate beyond L2 is not bounded by the HBM peak; "
-                                   "the HBM fraction is stated on the 1953 MiB tables"})
+            e.update({"traffic": None, "traffic_note": pmc_why or "no counter pass for this launch shape"})
         e.update({"chain_sweeps_per_s": (s.sweeps - s0.sweeps) / (kms / 1e3),
                   "accepted_moves_per_s": (s.accepted_moves - s0.accepted_moves) / (kms / 1e3)})
         out.append(e)
@@ -183,17 +201,15 @@ def hbm_regime(device, chains, theta=THETA):
          "peak": HBM_PEAK_GBS, "unit": "GB/s", "table_GBps": tab, "chain_sweeps_per_s": chains * 160 / (ms / 1e3),
          "lookups_per_s": look / (ms / 1e3), "gather_ceiling_GBps": 7200.0,
          "gather_ceiling_source": "profiles/r02_gather_probe_edge.txt (dependent random 1536-B rows of a 1465 MiB table, 4096 waves)"}
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("other", {}).get("edge")
-    except (OSError, ValueError):
-        t = None
+    t = None if pmc_all is None else pmc_all.get("other", {}).get("edge")
     if t and chains == 4096:
         ach = t["bytes_per_launch"] / (ms / 4 / 1e3) / 1e9
         e.update({"achieved": ach, "traffic": t["bytes_per_launch"], "frac": ach / HBM_PEAK_GBS, "frac_of_gather_ceiling": ach / 7200.0,
                   "achieved_note": "counter traffic beyond L2 per 40-sweep launch (table rows + the chains' K_curr / K_new columns), "
                                    "profiles/traffic.json, over the launch time of this run"})
     else:
-        e.update({"achieved": tab, "traffic": None, "frac": tab / HBM_PEAK_GBS})
+        e.update({"achieved": None, "traffic": None, "frac": None, "table_over_gather_ceiling": tab / 7200.0,
+                  "achieved_note": pmc_why or "no counter pass for this launch shape: only the table-row rate is stated"})
     out.append(e)
     h.close()
     return out
@@ -312,10 +328,18 @@ def main():
     hist_dev = torch.zeros(prob.n_grid, dtype=torch.float64, device="cuda")
     stat_dev = torch.zeros(8, dtype=torch.float64, device="cuda")
     min_dev = torch.zeros(1, dtype=torch.float64, device="cuda")
+    # RCCL ranks: the per-stage merge runs BEHIND the C ABI (sac_comm_init: one fused ncclAllReduce(sum) over
+    # [histogram | sum of Gbar | scalar sums | chain count] + one ncclAllReduce(min) at the end of every stage call, on the
+    # handle's stream); torch only carries the 128-byte unique id to the ranks.  The rehearsal (ranks sharing a GPU) cannot
+    # open an RCCL communicator and keeps the host-side merge below.
+    abi_merge = dist_on and not rehearse
+    if abi_merge:
+        from sac_amd.dist import Comm
+        Comm(device=torch.device("cuda", local_rank)).attach(h)
 
     def step():
         h.sample(args.sweeps_per_step, theta)
-        if dist_on:
+        if dist_on and not abi_merge:
             # per-stage merge (the only collective on the path): histogram + chi^2 statistics
             h.histogram_sum_to_device(hist_dev.data_ptr())
             st = h.stats()
@@ -367,17 +391,22 @@ def main():
         alg_bytes = cols_r0 * N_TAU * 8 + sweeps_r0 * N_OMEGA * 16   # K columns + histogram RMW
         per_launch_s = kernel_ms / 1e3 / n_l
         alg_gbps = alg_bytes / n_l / per_launch_s / 1e9
-        traffic = valu_qc = pmc = None
-        try:    # PMC counters of the same launch shape, collected in separate rocprofv3 passes
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            w = pmc["workload"]
-            if (w["n_tau"], w["n_omega"], w["n_grid"], w["chains"]) == (N_TAU, N_OMEGA, prob.n_grid, args.chains):
-                # per launch of THIS run: the profiled launch scaled by the sweeps a launch ran here
-                scale = sweeps_r0 / args.chains / n_l / w["sweeps_per_launch"]
-                traffic = (2.0 * pmc["fetch_size_kb_median"] + pmc["write_size_kb_median"]) * 1024.0 * scale
-                valu_qc = pmc["valu_active_quad_cycles_median"] * scale
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = valu_qc = None
+        # PMC counters of the same launch shape, collected in separate rocprofv3 passes ON THIS BUILD (else withheld)
+        pmc, pmc_why = load_traffic_json()
+        scale = 1.0
+        if pmc is not None:
+            try:
+                w = pmc["workload"]
+                if (w["n_tau"], w["n_omega"], w["n_grid"], w["chains"]) == (N_TAU, N_OMEGA, prob.n_grid, args.chains):
+                    # per launch of THIS run: the profiled launch scaled by the sweeps a launch ran here
+                    scale = sweeps_r0 / args.chains / n_l / w["sweeps_per_launch"]
+                    traffic = (2.0 * pmc["fetch_size_kb_median"] + pmc["write_size_kb_median"]) * 1024.0 * scale
+                    valu_qc = pmc["valu_active_quad_cycles_median"] * scale
+                else:
+                    pmc_why = "profiles/traffic.json holds another launch shape"
+            except KeyError as ex:
+                pmc_why = f"profiles/traffic.json lacks {ex}"
         if valu_qc is not None:
             ach = valu_qc / per_launch_s / 1e9
             roof = {"bound": "valu-issue", "achieved": ach, "peak": VALU_ISSUE_PEAK,
@@ -387,14 +416,19 @@ def main():
                     "salu_insts_per_proposal": pmc["salu_insts_median"] * scale / ((s1.proposals - s0.proposals) / n_l)}
         else:
             roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_ISSUE_PEAK,
-                    "unit": "G wave64 VALU issue quad-cycles/s", "frac": None}
+                    "unit": "G wave64 VALU issue quad-cycles/s", "frac": None, "achieved_null_reason": pmc_why}
         roof.update({"traffic": traffic,
                      "traffic_note": "bytes per launch beyond L2, (2*FETCH_SIZE+WRITE_SIZE)*1024 from profiles/traffic.json",
                      "hbm_frac": None if traffic is None else traffic / per_launch_s / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_GBps": alg_gbps, "algorithmic_over_hbm_peak": alg_gbps / HBM_PEAK_GBS,
                      "gather_ceiling_GBps": GATHER_CEILING_GBS, "algorithmic_over_gather_ceiling": alg_gbps / GATHER_CEILING_GBS,
-                     "gather_ceiling_source": "profiles/r02_gather_probe.txt (gather-only probe on the sampler's own column "
-                                              "distribution, 48.8 MiB table)",
+                     "gather_ceiling_source": GATHER_CEILING_SOURCE + " (gather-only probe on the sampler's own column distribution, "
+                                              "48.8 MiB table, 8 B per lane as the kernel loads; 16 B per lane / two rows per load: 18.8 TB/s)",
+                     # instruction-independent cross-check of the counter file: every gathered column is one wave load
+                     "columns_gathered_per_chain_sweep": cols_r0 / max(sweeps_r0, 1),
+                     "vmem_rd_per_chain_sweep_pmc": None if (pmc is None or "vmem_rd_insts_median" not in pmc) else
+                     pmc["vmem_rd_insts_median"] / (pmc["workload"]["chains"] * pmc["workload"]["sweeps_per_launch"]),
+                     "library_build_id": __import__("sac_amd.lib", fromlist=["build_id"]).build_id(),
                      "note": "table is cache resident: the algorithmic gather rate exceeds the HBM peak and is not a "
                              "roofline fraction; see hbm_regime for the HBM-bound shapes",
                      "kernel": "free_stage_kernel<1,false,true,false>", "chains_per_wave": h.chains_per_wave(), "launches": launches,
@@ -412,11 +446,12 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "chains_per_gpu": args.chains, "sweeps_per_step": args.sweeps_per_step,
                        "theta": theta, "parallelism": f"chains sharded over {world} GPU(s), "
-                                                      "one RCCL all-reduce per stage"},
+                                                      "one fused RCCL all-reduce(sum) + one all-reduce(min) per stage behind the C ABI"},
             "sweeps_per_s": sweeps / dt_max, "proposals_per_s": props / dt_max,
             "acceptance": {"evaluated_frac": evald / props, "accepted_moves_per_proposal": moves / props},
             "roofline": roof,
         }
+    h_comm_info = h.comm_info() if abi_merge else None
     h.close()
     if rank == 0:
         if world == 1 and not args.no_hbm_regime and not rehearse:
@@ -427,6 +462,8 @@ def main():
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
             out["speedup_note"] = f"one MI355X against {cb['cores']} host cores running the CPU port concurrently"
+        if abi_merge:
+            out["merge"] = dict(h_comm_info, where="behind the C ABI (sac_comm_init)")
         if dist_on and world == 1:
             out["collectives"] = "forced on with one rank (SAC_BENCH_FORCE_DIST=1): RCCL communicator, per-stage all-reduces and barrier executed"
         print(json.dumps(out))

@@ -116,6 +116,9 @@ typedef struct {
 } sac_move_rec_t;
 
 const char *sac_last_error(void);
+/* 16 hex digits: fingerprint of the sources this library was built from (Makefile).  No counterpart in the reference;
+ * bench.py quotes rocprofv3 counter files (profiles/traffic.json) only for the build they were measured on. */
+const char *sac_build_id(void);
 
 /* SAC(...) constructor, sampler fields only (free:5-76, 1191-1199). */
 int sac_create(const sac_config_t *cfg, sac_handle_t **out);
@@ -344,6 +347,8 @@ typedef struct {
                                        chain's); one chain: its chi2_min */
     int64_t  n_chains_total;        /* chains behind a chain = -1 result: n_chains, or the sum over ranks after
                                        sac_edge_comm_init */
+    int64_t  chains_below_target;   /* chain = -1: chains whose stage average <chi2> has fallen below their own target in some
+                                       stage since sac_edge_set_chain_targets (all ranks' after a merged stage); one chain: 0 / 1 */
 } sac_edge_results_t;
 
 int sac_edge_create(const sac_edge_config_t *cfg, sac_edge_t **out);
@@ -372,6 +377,19 @@ int sac_edge_init_gbar(sac_edge_t *h);
 int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, double theta);
 /* chain = -1: mean over chains (chi2_min: minimum; counters: sums) */
 int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_results_t *out);
+/* anneal(self, chi2_target) with many chains (edge:1646-1693, 1718).  The reference stops its second anneal the FIRST time
+ * its one chain's stage average <chi2> falls below chi2_target = chi2_min + a sqrt(2 chi2_min) -- a first passage of a
+ * noisy single-chain curve.  The many-chain equivalent is the median of the chains' own first passages: every chain
+ * gets its own target (from its own chi2_min), the library marks after every run_bins stage the chains whose stage
+ * average lies below their target (sticky), and sac_edge_get_results(-1).chains_below_target counts them over all chains
+ * (and ranks): the stage at which the count reaches half the chains is the median first passage.
+ *   sac_edge_set_targets_from_chi2_min: target_c = chi2_min_c + a sqrt(2 chi2_min_c) from the chains' current chi2_min
+ *   sac_edge_set_chain_targets: explicit targets[n_chains]; NULL switches the bookkeeping off
+ *   sac_edge_get_first_passages: per chain the 1-based index of the stage (counted from the set_* call) of its first
+ *   passage, 0 = not yet.  Setting targets clears the marks. */
+int sac_edge_set_targets_from_chi2_min(sac_edge_t *h, double a_criterion);
+int sac_edge_set_chain_targets(sac_edge_t *h, const double *targets);
+int sac_edge_get_first_passages(sac_edge_t *h, int32_t *stage);
 /* accept_rates[m, :, side] after the last adjust_D (edge:1386-1387): N_w+1 doubles */
 int sac_edge_get_accept_rates(sac_edge_t *h, int32_t chain, int32_t m, int32_t side, double *out);
 /* sampled_spec[:, which, side] (edge:75, 1322-1331): accumulated sums, N_wi doubles, chain mean */

@@ -480,12 +480,30 @@ __global__ void edge_cont_extent_kernel(const double *w, int n_chains, int S, in
     dst[t] = s;
 }
 
+// first passages of anneal(chi2_target) (edge:1680) per chain: marks the chains whose stage average <chi2> (chi2_res[1] / bins)
+// lies below their own target; pass[c] keeps the 1-based index of the first such stage
+__global__ void edge_passage_kernel(const EdgeScalars *sc, const double *targets, int *pass, int n_chains, double bins, int stage)
+{
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_chains) return;
+    if (pass[c] == 0 && sc[c].chi2_res[1] / bins < targets[c]) pass[c] = stage;
+}
+
+__global__ void edge_targets_kernel(const EdgeScalars *sc, double a, double *targets, int *pass, int n_chains)
+{
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= n_chains) return;
+    const double m = sc[c].chi2_min;
+    targets[c] = m + a * sqrt(2 * m);                               // edge:1718
+    pass[c] = 0;
+}
+
 constexpr int EDGE_SLOTS = 46;  // chi2_res[3], edge_res[6], n0_res[6], wn0_res[6], amp_ar[6], n0[2], eps0[2], dn0[2], deps0[2], chi2,
                                 // sum chi2_min, proposals, evaluated, accepted, lookups, violations, chains, sums of the lowest
-                                // and of the highest continuum frequency (43, 44), spare
+                                // and of the highest continuum frequency (43, 44), chains below their target (45)
 
 // one thread per slot: bin_averages (edge:1436-1449) of every chain, summed over the chains in index order
-__global__ void edge_pack_kernel(const EdgeScalars *sc, int n_chains, double bins, int n_rl, double *out_sum, double *out_min)
+__global__ void edge_pack_kernel(const EdgeScalars *sc, const int *pass, int n_chains, double bins, int n_rl, double *out_sum, double *out_min)
 {
     const int t = (int)threadIdx.x;
     if (t >= EDGE_SLOTS) return;
@@ -515,6 +533,7 @@ __global__ void edge_pack_kernel(const EdgeScalars *sc, int n_chains, double bin
         else if (t == 40) v = (double)x.counters[4];
         else if (t == 41) v = (double)x.violations;
         else if (t == 42) v = 1.0;
+        else if (t == 45) v = (pass != nullptr && pass[c] != 0) ? 1.0 : 0.0;     // chains below their own target so far
         s = s + v;
     }
     out_sum[t] = s;
@@ -550,6 +569,10 @@ struct sac_edge {
     saccomm::Comm *comm = nullptr; // sac_edge_comm_init: per-stage merge over ranks
     double *dGbarSum = nullptr;    // [128] sac_edge_get_gbar_mean without a communicator
     double *dMeans = nullptr;      // [4 n1 + 2] sac_edge_get_move_means without a communicator
+    double *dTargets = nullptr;    // [n_chains] per-chain chi2 targets of the second anneal (sac_edge_set_*targets*)
+    int *dPass = nullptr;          // [n_chains] 1-based stage index of each chain's first passage below its target, 0 = none
+    bool targets_on = false;
+    int stages_since_targets = 0;
     // layout of the fused merge buffer: [hist 4 n_grid | w_avg 2 n1 | A_avg 2 n1 | accept rates 4 n1 | sum of Gbar 128 |
     //                                    windows 2 n1 | cluster sizes 2 n1 | EDGE_SLOTS]
     size_t off_wavg() const { return 4 * (size_t)cfg.n_grid; }
@@ -648,6 +671,8 @@ extern "C" int sac_edge_create(const sac_edge_config_t *cfg, sac_edge_t **out)
     EALLOC(h->dLogLen, sizeof(unsigned long long));
     EALLOC(h->dGbarSum, SAC_MAX_N_TAU * sizeof(double));
     EALLOC(h->dMeans, (4 * ((size_t)cfg->n_omega + 1) + 2) * sizeof(double));
+    EALLOC(h->dTargets, nc * sizeof(double));
+    EALLOC(h->dPass, nc * sizeof(int));
 #undef EALLOC
     if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess) {
@@ -664,7 +689,7 @@ extern "C" int sac_edge_destroy(sac_edge_t *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->dTab[0], h->dTab[1], h->dG, h->dSinv, h->dW, h->dA, h->dDw, h->dMw, h->dNm, h->dArc, h->dKcurr,
-                    h->dKnew, h->dGbar, h->dWavg, h->dAavg, h->dHist, h->dSc, h->dLog, h->dLogLen, h->dGbarSum, h->dMeans};
+                    h->dKnew, h->dGbar, h->dWavg, h->dAavg, h->dHist, h->dSc, h->dLog, h->dLogLen, h->dGbarSum, h->dMeans, h->dTargets, h->dPass};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     saccomm::destroy(h->comm);
@@ -947,8 +972,9 @@ static int edge_comm_merge(sac_edge *h)
                        (const double *)h->dDw, nc, 2ll * S, 2, S, n1, c->dSum + h->off_dw());
     hipLaunchKernelGGL(edge_sum_chains_int_kernel, dim3((unsigned)((2 * n1 + 255) / 256)), dim3(256), 0, h->stream,
                        (const int *)h->dNm, nc, 2ll * S, 2, S, n1, c->dSum + h->off_nm());
-    hipLaunchKernelGGL(edge_pack_kernel, dim3(1), dim3(64), 0, h->stream, (const EdgeScalars *)h->dSc, nc, (double)h->last_bins,
-                       h->cfg.n_rl, c->dSum + h->n_payload(), c->dMin);
+    hipLaunchKernelGGL(edge_pack_kernel, dim3(1), dim3(64), 0, h->stream, (const EdgeScalars *)h->dSc,
+                       (const int *)(h->targets_on ? h->dPass : nullptr), nc, (double)h->last_bins, h->cfg.n_rl,
+                       c->dSum + h->n_payload(), c->dMin);
     if (h->cfg.n_omega > h->cfg.n_e)      // after the pack kernel in stream order: it writes 0 into slots 43, 44
         hipLaunchKernelGGL(edge_cont_extent_kernel, dim3(1), dim3(64), 0, h->stream, (const double *)h->dW, nc, S, h->cfg.n_e,
                            h->cfg.n_omega, c->dSum + h->n_payload() + 43);
@@ -1011,6 +1037,14 @@ extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, dou
     if (steps * bins > 0 && ms > 0.f) h->ms_per_sweep = (double)ms / (double)(steps * bins);
     h->last_steps = steps;
     h->last_bins = bins;
+    if (h->targets_on) {                                     // first passages below the chains' own targets (edge:1680)
+        h->stages_since_targets += 1;
+        hipLaunchKernelGGL(edge_passage_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream,
+                           (const EdgeScalars *)h->dSc, (const double *)h->dTargets, h->dPass, (int)nc, (double)bins,
+                           h->stages_since_targets);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
     return edge_comm_merge(h);
 }
 
@@ -1067,6 +1101,7 @@ extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_resul
         out->proposals = (uint64_t)t[37]; out->evaluated = (uint64_t)t[38]; out->accepted = (uint64_t)t[39];
         out->lookups = (uint64_t)t[40]; out->violations = (uint64_t)t[41];
         out->n_chains_total = (int64_t)n;
+        out->chains_below_target = (int64_t)t[45];
         EdgeScalars last;
         HIP_TRY(hipMemcpy(&last, h->dSc + (nc - 1), sizeof(last), hipMemcpyDeviceToHost));
         out->sweeps = last.sweep;
@@ -1103,6 +1138,11 @@ extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_resul
         out->lookups += s.counters[4]; out->violations += s.violations;
     }
     out->n_chains_total = count;
+    if (h->targets_on) {
+        std::vector<int> pass((size_t)count);
+        HIP_TRY(hipMemcpy(pass.data(), h->dPass + first, pass.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int v : pass) out->chains_below_target += (v != 0) ? 1 : 0;
+    }
     out->last_stage_ms = h->last_stage_ms;
     return SAC_OK;
 }
@@ -1397,6 +1437,49 @@ extern "C" int sac_edge_comm_info(sac_edge_t *h, int32_t *rank, int32_t *world, 
     if (world) *world = h->comm ? h->comm->world : 1;
     if (merges) *merges = h->comm ? h->comm->merges : 0;
     if (allreduce_calls) *allreduce_calls = h->comm ? h->comm->allreduce_calls : 0;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_set_targets_from_chi2_min(sac_edge_t *h, double a_criterion)
+{
+    if (!h || !std::isfinite(a_criterion)) return efail(SAC_E_INVALID, "sac_edge_set_targets_from_chi2_min: bad argument");
+    if (!h->gbar_set) return efail(SAC_E_STATE, "sac_edge_set_targets_from_chi2_min: no chi2_min yet (sac_edge_init_gbar first)");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    const int nc = h->cfg.n_chains;
+    hipLaunchKernelGGL(edge_targets_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, h->stream,
+                       (const EdgeScalars *)h->dSc, a_criterion, h->dTargets, h->dPass, nc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->targets_on = true;
+    h->stages_since_targets = 0;
+    if (h->comm) h->comm->merged = false;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_set_chain_targets(sac_edge_t *h, const double *targets)
+{
+    if (!h) return efail(SAC_E_INVALID, "sac_edge_set_chain_targets: null handle");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t nc = (size_t)h->cfg.n_chains;
+    HIP_TRY(hipMemset(h->dPass, 0, nc * sizeof(int)));
+    h->targets_on = (targets != nullptr);
+    h->stages_since_targets = 0;
+    if (targets) HIP_TRY(hipMemcpy(h->dTargets, targets, nc * sizeof(double), hipMemcpyHostToDevice));
+    if (h->comm) h->comm->merged = false;
+    return SAC_OK;
+}
+
+extern "C" int sac_edge_get_first_passages(sac_edge_t *h, int32_t *stage)
+{
+    if (!h || !stage) return efail(SAC_E_INVALID, "sac_edge_get_first_passages: null argument");
+    int rc;
+    if ((rc = use_device(h))) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
+    HIP_TRY(hipMemcpy(stage, h->dPass, (size_t)h->cfg.n_chains * sizeof(int), hipMemcpyDeviceToHost));
     return SAC_OK;
 }
 

@@ -833,6 +833,11 @@ struct sac_handle {
 
 extern "C" const char *sac_last_error(void) { return g_err; }
 
+#ifndef SAC_BUILD_ID
+#define SAC_BUILD_ID "unknown"
+#endif
+extern "C" const char *sac_build_id(void) { return SAC_BUILD_ID; }
+
 // host code changed the chains: the merged view of the last stage (comm_merge) no longer describes them
 static void drop_merged(sac_handle *h)
 {

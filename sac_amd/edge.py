@@ -357,8 +357,10 @@ class EdgeSAC:
             r = self.res
             keys = ("chi2_res", "edge_res", "n0_res", "wn0_res", "amp_ar", "n0", "eps0", "dn0", "deps0", "chi2", "chi2_min_mean")
             m = self.comm.merge_named(self.n_chains, {k: r[k] for k in keys}, mins={"chi2_min": r["chi2_min"]},
-                                      sums={"violations": r["violations"]})
+                                      sums={"violations": r["violations"], "chains_below_target": r["chains_below_target"]})
             self.res = dict(r, **m)
+            self.res["n_chains_total"] = m["n_chains"]
+            self.res["chains_below_target"] = int(round(m["chains_below_target"]))
         self.chi2_min_all = self.res["chi2_min"]
         self.chi2_min = self.res["chi2_min_mean"] if self.chi2_min_mode == "chain_mean" else self.res["chi2_min"]
         if self.res["violations"]:
@@ -496,7 +498,12 @@ class EdgeSAC:
             f.write(f"{fl(w + dwh2 / 2.0)},0,0,0\n")
 
     # ---- annealing routines --------------------------------------------------------------
-    def anneal(self, chi2_target, bins, spec):                              # edge:1646-1693
+    def anneal(self, chi2_target, bins, spec, first_passage=False):         # edge:1646-1693
+        """first_passage (no counterpart in the one-chain reference): the target rule of the second anneal is taken chain by
+        chain -- every chain has its own target (sac_edge_set_targets_from_chi2_min) and the anneal stops at the stage in
+        which half of all chains have had their stage average below it, i.e. at the MEDIAN of the chains' first passages.
+        The reference's rule `chi2_res[2] < chi2_target` (edge:1680) is the first passage of its one chain's noisy curve;
+        with one chain both rules are the same test."""
         theta = self.theta_0
         i_trans = self.N_anneal * 0.2
         nt = self.td.n_tau
@@ -513,7 +520,11 @@ class EdgeSAC:
             if i == 5:                                                      # edge:1671-1675
                 self.saved = [self.h.get_state(c) for c in range(self.n_chains)]
             chi2_avg = self.res["chi2_res"][1]
-            if chi2_avg < chi2_target:
+            if first_passage:
+                reached = 2 * self.res["chains_below_target"] >= self.res["n_chains_total"]
+            else:
+                reached = chi2_avg < chi2_target
+            if reached:
                 return theta * self.f_anneal
             elif (chi2_avg - self.chi2_min) < (self.tol * nt):
                 return theta
@@ -533,10 +544,17 @@ class EdgeSAC:
         self.anneal(0.0, self.bins, 0)
         self.write_log("Main Anneal Finished.")
         chi2_target = self.chi2_min + self.a_criterion * math.sqrt(2 * self.chi2_min)
+        # chain_mean mode: every chain gets its own target from its own chi2_min (before the restore resets chi2_min, edge:1730)
+        first_passage = self.chi2_min_mode == "chain_mean"
+        if first_passage:
+            self.h.set_targets_from_chi2_min(self.a_criterion)
         if self.saved is not None:
             self._restore_saved()
         self.write_log("Beginning Final Anneal.")
-        theta_opt = self.anneal(chi2_target, self.bins, 0)
+        theta_opt = self.anneal(chi2_target, self.bins, 0, first_passage=first_passage)
+        if first_passage:
+            self.first_passages = self.h.first_passages()                   # this rank's chains: stage index of each first passage
+            self.h.set_chain_targets(None)
         self.write_log("Final Anneal Finished.")
         self.write_log("Beginning Final Sampling.")
         bins = 10

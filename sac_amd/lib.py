@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("SAC_HIP_LIB") or os.path.join(_HERE, "libsac_hip.so")
 _LIB = None
 
 EXPORTS = [
-    "sac_last_error", "sac_create", "sac_destroy", "sac_upload_problem", "sac_set_state",
+    "sac_last_error", "sac_build_id", "sac_create", "sac_destroy", "sac_upload_problem", "sac_set_state",
     "sac_get_state", "sac_init_gbar", "sac_get_gbar", "sac_set_gbar", "sac_adjust_windows",
     "sac_sample", "sac_get_stats", "sac_get_chain_stats", "sac_get_histogram",
     "sac_get_histogram_sum_device", "sac_set_move_log", "sac_get_move_log",
@@ -21,7 +21,8 @@ EXPORTS = [
     "sac_edge_get_move_log",
     "sac_build_table", "sac_build_table_noalloc", "sac_get_table", "sac_upload_data",
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
-    "sac_get_gbar_mean", "sac_edge_get_gbar_mean", "sac_edge_get_move_means", "sac_comm_unique_id", "sac_comm_init", "sac_comm_info", "sac_edge_comm_init", "sac_edge_comm_info",
+    "sac_get_gbar_mean", "sac_edge_get_gbar_mean", "sac_edge_get_move_means",
+    "sac_edge_set_targets_from_chi2_min", "sac_edge_set_chain_targets", "sac_edge_get_first_passages", "sac_comm_unique_id", "sac_comm_init", "sac_comm_info", "sac_edge_comm_init", "sac_edge_comm_info",
     "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_set_proposals_per_step", "sac_get_proposals_per_step", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
 ]
 
@@ -82,7 +83,7 @@ class EdgeResults(C.Structure):
                 ("sweeps", C.c_uint64), ("proposals", C.c_uint64), ("evaluated", C.c_uint64),
                 ("accepted", C.c_uint64), ("lookups", C.c_uint64), ("violations", C.c_uint64),
                 ("last_stage_ms", C.c_double),
-                ("chi2_min_mean", C.c_double), ("n_chains_total", C.c_int64)]
+                ("chi2_min_mean", C.c_double), ("n_chains_total", C.c_int64), ("chains_below_target", C.c_int64)]
 
 
 COMM_ID_BYTES = 128     # SAC_COMM_ID_BYTES
@@ -123,6 +124,7 @@ def load_library():
     L = C.CDLL(LIB_PATH)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)
     L.sac_last_error.restype = C.c_char_p
+    L.sac_build_id.restype = C.c_char_p
     L.sac_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.sac_destroy.argtypes = [vp]
     L.sac_upload_problem.argtypes = [vp, dp, dp, dp]
@@ -163,6 +165,9 @@ def load_library():
     L.sac_get_gbar_mean.argtypes = [vp, dp]
     L.sac_edge_get_gbar_mean.argtypes = [vp, dp]
     L.sac_edge_get_move_means.argtypes = [vp, dp, dp, dp]
+    L.sac_edge_set_targets_from_chi2_min.argtypes = [vp, C.c_double]
+    L.sac_edge_set_chain_targets.argtypes = [vp, dp]
+    L.sac_edge_get_first_passages.argtypes = [vp, C.POINTER(C.c_int32)]
     i32p = C.POINTER(C.c_int32)
     L.sac_comm_unique_id.argtypes = [vp]
     L.sac_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
@@ -189,10 +194,15 @@ def load_library():
     L.sac_edge_replay.argtypes = [vp, C.c_int32, C.c_double, vp, C.c_int64, dp, C.c_int64, dp, vp]
     L.sac_edge_get_move_log.argtypes = [vp, vp, C.c_int64, ip]
     for name in EXPORTS:
-        if name != "sac_last_error":
+        if name not in ("sac_last_error", "sac_build_id"):
             getattr(L, name).restype = C.c_int
     _LIB = L
     return L
+
+
+def build_id():
+    """sac_build_id(): fingerprint of the sources the loaded library was built from."""
+    return load_library().sac_build_id().decode()
 
 
 def comm_unique_id():
@@ -578,7 +588,7 @@ class SacEdgeHandle:
         return dict(chi2_res=np.array(r.chi2_res[:]), edge_res=f(r.edge_res), n0_res=f(r.n0_res), wn0_res=f(r.wn0_res),
                     amp_ar=f(r.amp_accept_rates), n0=np.array(r.n0[:]), eps0=np.array(r.eps0[:]),
                     dn0=np.array(r.dn0[:]), deps0=np.array(r.deps0[:]), chi2=r.chi2, chi2_min=r.chi2_min,
-                    chi2_min_mean=r.chi2_min_mean, n_chains_total=r.n_chains_total,
+                    chi2_min_mean=r.chi2_min_mean, n_chains_total=r.n_chains_total, chains_below_target=r.chains_below_target,
                     sweeps=r.sweeps, proposals=r.proposals, evaluated=r.evaluated, accepted=r.accepted,
                     lookups=r.lookups, violations=r.violations, last_stage_ms=r.last_stage_ms)
 
@@ -597,6 +607,24 @@ class SacEdgeHandle:
         w, A = np.empty(2 * n1), np.empty(2 * n1)
         self._check(self.L.sac_edge_get_avg(self.h, chain, _dp(w), _dp(A)))
         return w.reshape(2, n1).T.copy(), A.reshape(2, n1).T.copy()
+
+    def set_targets_from_chi2_min(self, a_criterion):
+        """Every chain's own target chi2_min_c + a sqrt(2 chi2_min_c) (edge:1718) for the first-passage bookkeeping of the
+        second anneal; clears the marks."""
+        self._check(self.L.sac_edge_set_targets_from_chi2_min(self.h, float(a_criterion)))
+
+    def set_chain_targets(self, targets=None):
+        t = None if targets is None else np.ascontiguousarray(targets, dtype=np.float64)
+        if t is not None and t.shape != (self.cfg.n_chains,):
+            raise SacError(f"targets has shape {t.shape}, expected ({self.cfg.n_chains},)")
+        self._check(self.L.sac_edge_set_chain_targets(self.h, _dp(t)))
+
+    def first_passages(self):
+        """Per chain the 1-based index of the stage (since the targets were set) in which its stage average first fell below
+        its target; 0 = not yet."""
+        out = np.zeros(self.cfg.n_chains, dtype=np.int32)
+        self._check(self.L.sac_edge_get_first_passages(self.h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     def move_means(self):
         """Chain means (all ranks' after a merged stage) of the per-delta windows and cluster sizes, [N_w+1, 2] each, and

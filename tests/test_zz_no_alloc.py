@@ -58,19 +58,28 @@ def test_noalloc_argument_errors():
     h.close()
 
 
+def _hip_free_bytes():
+    """hipMemGetInfo through the HIP runtime libsac_hip.so itself is linked against (found in this process's maps: a second
+    runtime -- torch's bundled one -- cannot open the GPU beside it)."""
+    import ctypes
+    path = next(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln)
+    hip = ctypes.CDLL(path)
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipDeviceSynchronize() == 0
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
 def test_noalloc_call_leaves_free_device_memory_unchanged():
-    """The point of the entry: no device allocation.  hipMemGetInfo (through torch.cuda.mem_get_info) before and after a call
-    on a warmed-up handle (the first call may load code objects) must read the same number of free bytes, for the largest
-    supported N_tau; the allocating entry point is not required to (and is not checked)."""
-    import torch
+    """The point of the entry: no device allocation.  hipMemGetInfo before and after calls on a warmed-up handle (the first
+    call may load code objects) must read the same number of free bytes, for the largest supported N_tau; the allocating
+    entry point is not required to (and is not checked)."""
     big = synthetic_timedata(n_tau=128, seed=5, n_boot=500)
     h = SacHandle(big.n_tau, 40, 4001, 0, 4000)
     h.build_table(0, "bosonic", big.tau, big.beta, big.cov, 0, 2e-3, noalloc=True)      # warm-up
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info(0)
+    free0 = _hip_free_bytes()
     for _ in range(3):
         h.build_table(0, "bosonic", big.tau, big.beta, big.cov, 0, 2e-3, noalloc=True)
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info(0)
+    free1 = _hip_free_bytes()
     assert free1 == free0, (free0, free1)
     h.close()

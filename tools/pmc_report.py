@@ -112,8 +112,12 @@ def main():
                    "workload": {"n_tau": 64, "n_omega": 2000, "n_grid": 100001, "chains": 4096, "sweeps_per_launch": 100},
                    "fetch_size_kb_median": use["FETCH_SIZE"], "write_size_kb_median": use["WRITE_SIZE"],
                    "valu_active_quad_cycles_median": use["SQ_ACTIVE_INST_VALU"], "valu_insts_median": use["SQ_INSTS_VALU"],
-                   "salu_insts_median": use["SQ_INSTS_SALU"],
+                   "salu_insts_median": use["SQ_INSTS_SALU"], "vmem_rd_insts_median": use.get("SQ_INSTS_VMEM_RD"),
                    "source": source,
+                   # sac_build_id() of the library that ran under the profiler (the PMC script writes it next to the passes):
+                   # bench.py quotes these numbers only when the library it runs has the same id
+                   "build_id": (open(os.path.join(SRC, "build_id.txt")).read().strip()
+                                if os.path.exists(os.path.join(SRC, "build_id.txt")) else None),
                    "hbm_regime": {"free_1000001": traffic.get("hbm1"), "free_4000001": traffic.get("hbm4"), "peak_1000001": traffic.get("pkhb"), "peak_4000001": traffic.get("pkh4")},
                    "other": {"peak_two_axes": traffic.get("pk2"), "peak_bench_param": traffic.get("peak"), "edge": traffic.get("edge"), "free_packed_ntau22": traffic.get("pack")}},
                   open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=2)

@@ -106,4 +106,12 @@ elif what == "edge":
            "anneal_points_first_pass": [len(g1), len(r1)],
            "chi2_ratio_last": float(g1[n - 1, 3] / r1[n - 1, 3]),
            "theta_opt": [float(theta_opt), float(rs[1])], "chi2_avg_final": [float(gs[3]), float(rs[3])], "edge_final": [float(gs[5]), float(rs[5])]}
+    fp = getattr(s, "first_passages", None)
+    if fp is not None:
+        # theta of every chain's own first passage below its own target (0 = none before the anneal stopped): the reference's
+        # theta_opt is ONE draw from this distribution
+        th = np.array([s.theta_0 / s.f_anneal ** (k - 2) for k in fp if k > 0])      # anneal returns theta * f_anneal (edge:1681)
+        out["first_passage_theta"] = {"chains_crossed": int((fp > 0).sum()), "min": float(th.min()), "p10": float(np.percentile(th, 10)),
+                                      "median": float(np.median(th)), "p90": float(np.percentile(th, 90)), "max": float(th.max()),
+                                      "reference_theta_opt_percentile": float((th <= float(rs[1])).mean())}
 print(json.dumps(out))
