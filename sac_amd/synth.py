@@ -62,3 +62,43 @@ def synthetic_timedata(n_tau=64, beta=128.0, seed=12345, n_bins=1000, n_boot=100
     evecs = evecs / np.linalg.norm(evecs, axis=0)[None, :]
     eig_sigma = np.sqrt(np.maximum(evals, 1e-300) / n_boot)         # 146
     return TimeData(beta, n_boot, norm, tau, mean, sigma_bar, eig_sigma, evecs)
+
+
+# --------------------------------------------------------------------------------------------
+# Row f4: the reference's synthetic-data recipe restated (sac/process_G/synthetic/generate_synth.jl,
+# "gs:NNN"): G(tau) of a tabulated spectrum, then bins with tau-correlated noise.
+# --------------------------------------------------------------------------------------------
+
+def make_G_tau(omega, S, tau, beta, kernel_type="bosonic", peaks=()):
+    """make_G_tau (gs:534-654) for a spectrum given as a table: G0(tau_j) = (1 / pi) [ int S(w) K(w, tau_j) dw +
+    sum_p A_p K(w_p, tau_j) ] (gs:638: G0_val / pi; delta peaks enter as A0 K(w0, tau), gs:596-599).  The reference integrates
+    its analytic spectrum with QuadGK at rtol 1e-13; here the table it wrote (aw.dat, spacing 4e-4) is integrated by the
+    trapezoid rule -- error ~ 1e-8 relative, the rounding of cor.dat.  tau includes tau = 0 (gs:585: j = 0..N_tau)."""
+    omega, S, tau = np.asarray(omega, dtype=np.float64), np.asarray(S, dtype=np.float64), np.asarray(tau, dtype=np.float64)
+    K = kernel_values(kernel_type, omega, tau, beta)                    # [len(omega), len(tau)]
+    G = np.trapezoid(S[:, None] * K, omega, axis=0)
+    for w_p, A_p in peaks:
+        G = G + A_p * kernel_values(kernel_type, [w_p], tau, beta)[0]
+    return G / np.pi
+
+
+def noise_mixing(tau, xi):
+    """The matrix of add_noise (gs:672-685): row j = exp(-|tau_i - tau_j| / xi) / sqrt(sum_i exp(...)^2)."""
+    tau = np.asarray(tau, dtype=np.float64)
+    C = np.exp(-np.abs(tau[:, None] - tau[None, :]) / xi)
+    return C / np.sqrt((C ** 2).sum(axis=1))[:, None]
+
+
+def add_noise(G0, tau, rel_sigma, xi, rng, n_bins=1):
+    """add_noise (gs:657-687), default branch: sigma = rel_sigma * 2 G0[tau = 0] (gs:669); white noise of that size per tau
+    point, mixed with the exponential tau correlation; every point keeps variance sigma^2.  Returns [n_bins, len(tau)]."""
+    G0 = np.asarray(G0, dtype=np.float64)
+    sig = rel_sigma * (G0[0] * 2)
+    white = rng.standard_normal((n_bins, len(G0))) * sig
+    return G0[None, :] + white @ noise_mixing(tau, xi).T
+
+
+def noise_covariance(G0, tau, rel_sigma, xi):
+    """Covariance of the bins add_noise draws: sigma^2 M M^T with M = noise_mixing."""
+    M = noise_mixing(tau, xi)
+    return (rel_sigma * 2 * G0[0]) ** 2 * (M @ M.T)

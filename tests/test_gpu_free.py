@@ -36,6 +36,9 @@ CASES = [
     ("synth_ntau64_n2000", dict(kind="synth", n_tau=64, n_omega=2000), 1.0, 10, 6),
     ("synth_ntau40_finiteT", dict(kind="synth", n_tau=40, n_omega=333, kernel_type="finiteT",
                                   omega_0=-6.0, omega_m=6.0, d_omega=1e-3), 5.0, 20, 10),
+    # BASELINE.json configs[0]'s shape: fermionic (finite-T) data, N_tau = 40, 1000 delta functions
+    ("configs0_ntau40_finiteT_n1000", dict(kind="synth", n_tau=40, n_omega=1000, kernel_type="finiteT",
+                                           omega_0=-6.0, omega_m=6.0, d_omega=1e-3), 2.0, 10, 5),
     ("synth_ntau80_zeroT", dict(kind="synth", n_tau=80, n_omega=500, kernel_type="zeroT",
                                 omega_0=-2.0, omega_m=8.0, d_omega=1e-3), 3.0, 20, 10),
     ("synth_ntau102_symm", dict(kind="synth", n_tau=102, n_omega=100, kernel_type="finiteT",

@@ -28,6 +28,10 @@ def main():
     np.savez_compressed(f"{OUT}/bins.npz", q=q)
     shutil.copyfile(f"{SRC}/tgrid.dat", f"{OUT}/tgrid.dat")
     shutil.copyfile(f"{SRC}/t.in", f"{OUT}/t_ref.in")
+    # the true spectrum the reference's generator wrote next to its bins (omega, S; rows 1-2 mark the delta peak as a spike of
+    # height A0 / spacing): data for the restated make_G_tau / add_noise (sac_amd/synth.py, tests/test_synth_recipe.py)
+    aw = np.loadtxt(f"{SRC}/aw.dat", delimiter=",", skiprows=1)
+    np.savez_compressed(f"{OUT}/aw.npz", omega=aw[:, 0], S=aw[:, 1])
     os.system(f"chmod -R u+w {OUT}")
 
 
