@@ -225,10 +225,17 @@ __global__ void __launch_bounds__(64 * WAVES_PER_BLOCK) init_gbar_kernel(const F
 // transfer between the axes); they are read and written in place in global memory (16 KB per chain at
 // 2 x 1001 deltas, L2 resident), so that LDS holds the positions only and 16 chains stay resident per CU.
 
+#ifdef PEAK_PROF   // development aid (as EDGE_PROF): cycles per section of chain 0's sweep, printed at the end of the launch
+#define PEAK_NSC 42
+#define PEAK_TICK(i) do { const unsigned long long now_ = clock64(); if (lane == 0) reinterpret_cast<unsigned long long *>(s_sc_w + 26)[i] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define PEAK_NSC 26
+#define PEAK_TICK(i) do { } while (0)
+#endif
 __host__ __device__ constexpr size_t peak_lds_bytes_per_wave(int wi_stride, bool xfer)
 {
     (void)xfer;                     // the transfer variants keep their amplitudes in global memory (L2)
-    return (size_t)wi_stride * 4u + 26u * 8u;
+    return (size_t)wi_stride * 4u + (size_t)PEAK_NSC * 8u;
 }
 
 template <int NTL, bool LOG, bool XFER>
@@ -243,10 +250,14 @@ peak_stage_kernel(const PeakParams pp)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *s_mine = s_dyn + (size_t)wave * peak_lds_bytes_per_wave(p.wi_stride, XFER);
     double *s_sc_w = reinterpret_cast<double *>(s_mine);
-    uint32_t *s_wi_w = reinterpret_cast<uint32_t *>(s_sc_w + 26);
+    uint32_t *s_wi_w = reinterpret_cast<uint32_t *>(s_sc_w + PEAK_NSC);
     const int chain = (int)blockIdx.x * WPB + wave;
     if (chain >= p.n_chains) return;
     const int lane = lane_id();
+#ifdef PEAK_PROF
+    if (lane < 16) reinterpret_cast<unsigned long long *>(s_sc_w + 26)[lane] = 0ull;
+    unsigned long long tprev = clock64();
+#endif
     const int n_p = pp.n_p, n = pp.n_cont;
     const int n_used = pp.sample_neg ? 2 * (n_p + n) : (n_p + n);
     const char *Kp = reinterpret_cast<const char *>(p.K), *Kn = reinterpret_cast<const char *>(pp.Kn);
@@ -312,7 +323,9 @@ peak_stage_kernel(const PeakParams pp)
     for (int s = 0; s < p.n_sweeps; ++s) {
         c.sweep_lo = (uint32_t)sweep;
         c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
+        PEAK_TICK(9);
         peak_refresh_gbar<NTL>(c, Kp, Kn, A, n_p, n, pp.sample_neg);
+        PEAK_TICK(0);
         if (pp.refresh_bounds) {                                     // peak:1074-1075
             b_pp = group_max(c.wi, f_pp, n_p, lane);
             if (pp.sample_neg) b_np = group_max(c.wi, f_pn, n_p, lane);
@@ -330,6 +343,7 @@ peak_stage_kernel(const PeakParams pp)
                     a = xfer_loop<1, (NTL == 1) ? 4 : 2, NTL, LOG>(c, Kp, Kn, A, sp, n / 2);
                     n_prop += n / 2;
                     if (lane == 0) acc[5] += (double)a / (double)(n / 2);
+                    PEAK_TICK(1);
                     b_pc = group_min(c.wi, f_cp, n, lane);           // peak:787-788
                     b_nc = group_min(c.wi, f_cn, n, lane);
                     sp.move_id = 20;                                 // peak_Aw_transfer, peak:798-880
@@ -340,9 +354,11 @@ peak_stage_kernel(const PeakParams pp)
                     a = xfer_loop<1, (NTL == 1) ? 4 : 2, NTL, LOG>(c, Kp, Kn, A, sp, 10);
                     n_prop += 10;
                     if (lane == 0) acc[6] += (double)a / 10.0;
+                    PEAK_TICK(2);
                     b_pp = group_max(c.wi, f_pp, n_p, lane);         // peak:876-877
                     b_np = group_max(c.wi, f_pn, n_p, lane);
                 }
+                PEAK_TICK(9);
                 XferSpec<2> sp;                                      // Aw_transfer, peak:882-996
                 sp.move_id = 21;
                 sp.first[0] = f_cp; sp.count[0] = n; sp.first[1] = f_cn; sp.count[1] = n;
@@ -355,6 +371,7 @@ peak_stage_kernel(const PeakParams pp)
                 a = xfer_loop<2, 2, NTL, LOG>(c, Kp, Kn, A, sp, n / 2);
                 n_prop += n / 2;
                 if (lane == 0) acc[10] += (double)a / (double)(n / 2);
+                PEAK_TICK(3);
             }
         }
         for (int pn = 1; pn <= (pp.sample_neg ? 2 : 1); ++pn) {      // peak:1037-1047
@@ -364,12 +381,16 @@ peak_stage_kernel(const PeakParams pp)
             c.k_count = n;
             c.lo = ((pn == 1) ? b_pp : b_np) + 1;                    // new <= floor(w_b): continue (peak:409)
             c.hi = wim;
+            PEAK_TICK(9);
             a = move_loop<1, D1, NTL, LOG, false>(c, 11 + pn - 1, n, win[0 + o7]);
             if (lane == 0) acc[0 + o7] += (double)a / (double)n;
+            PEAK_TICK(4);
             a = move_loop<2, D2, NTL, LOG, false>(c, 13 + pn - 1, n / 2, win[1 + o7]);
             if (lane == 0) acc[1 + o7] += (double)(2 * a) / (double)(n / 2);
+            PEAK_TICK(5);
             a = move_loop<3, D3, NTL, LOG, false>(c, 15 + pn - 1, n / 3, 0.0);
             if (lane == 0) acc[2 + o7] += (double)a / (double)(n / 3);
+            PEAK_TICK(6);
             n_prop += n + n / 2 + n / 3;
             const int m = group_min(c.wi, c.k_first, n, lane);       // peak:440-444
             if (pn == 1) b_pc = m; else b_nc = m;
@@ -388,6 +409,7 @@ peak_stage_kernel(const PeakParams pp)
                 if (pn == 1) b_pp = m; else b_np = m;
             }
         }
+        PEAK_TICK(7);
         if (p.flags & STAGE_SAMPLE) {
             for (int i = lane; i < n_used; i += 64) {                // peak:1126-1140
                 const int which = (i >= f_cn) ? 3 : (i >= f_pn) ? 2 : (i >= f_cp) ? 1 : 0;
@@ -401,8 +423,16 @@ peak_stage_kernel(const PeakParams pp)
                 edge[1] += (double)b_np;
             }
         }
+        PEAK_TICK(8);
         sweep += 1;
     }
+#ifdef PEAK_PROF
+    if (chain == 0 && lane == 0 && p.n_sweeps > 1) {
+        const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(s_sc_w + 26);
+        printf("peak prof sweeps=%d cycles: refresh_gbar %llu | cont_xfer %llu peak_xfer %llu Aw_transfer %llu | cont single %llu double %llu triple %llu | "
+               "peak moves %llu | sample %llu | other %llu\n", p.n_sweeps, pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[6], pr[7], pr[8], pr[9]);
+    }
+#endif
 
     if ((p.flags & STAGE_RETUNE) && lane == 0) {                     // peak:1079-1091
         for (int k = 0; k < 11; ++k) acc[k] = acc[k] / p.retune_div;
