@@ -237,8 +237,18 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
                 const int nw = inb ? __builtin_amdgcn_readlane(d.wnew[q], jj) : o;
                 is_old[u][q] = o;
                 is_new[u][q] = nw;
-                load_col<NTL>(c, nw, kn[u][q]);
-                load_col<NTL>(c, o, ko[u][q]);
+                if constexpr (UA) {
+                    load_col<NTL>(c, nw, kn[u][q]);
+                    load_col<NTL>(c, o, ko[u][q]);
+                } else {
+                    // A proposal that is out of bounds is never evaluated (free:296), but its two loads must still be issued
+                    // (the waits count outstanding loads statically): they are parked on column 0, which stays in the CU's
+                    // vector cache, instead of fetching the delta's old column -- a random 512-B row -- from HBM for nothing.
+                    // Matters where many proposals fall outside the bounds (the two-axis peak runs: 59 %).
+                    const bool live = inb && (j < cnt);
+                    load_col<NTL>(c, live ? nw : 0, kn[u][q]);
+                    load_col<NTL>(c, live ? o : 0, ko[u][q]);
+                }
             }
         };
         auto resolve = [&](auto U, int j) {

@@ -214,8 +214,9 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
                 const int nw = inb ? __builtin_amdgcn_readlane(d.wnew[e], jj) : o;
                 is_old[u][e] = o;
                 is_new[u][e] = nw;
-                fetch(e, nw, kn[u][e]);
-                fetch(e, o, ko[u][e]);
+                const bool live = inb && (j < cnt);       // never evaluated otherwise: park the loads on column 0 (free_sweep.h)
+                fetch(e, live ? nw : 0, kn[u][e]);
+                fetch(e, live ? o : 0, ko[u][e]);
             }
         };
         auto resolve = [&](auto U, int j) {
