@@ -40,6 +40,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 GATHER_CEILING_GBS = 16467.5
 GATHER_CEILINGS_BY_GRID = {1000001: 9728.6, 4000001: 8133.9}
 GATHER_CEILING_SOURCE = "profiles/r03_gather_probe.txt"
+# the same probe on the sac/peak samplers' column distributions (tools/dump_positions_peak.py; the continuum deltas of a peak run
+# crowd behind the peak: fewer distinct columns per chain, hence higher ceilings than sac/free's on the same table size);
+# "two" = both axes, the two 488 MiB tables as one 976.6 MiB footprint
+PEAK_GATHER_CEILINGS = {1000001: 11607.4, 4000001: None, "two_axes_1000001": 12543.0}
+PEAK_GATHER_CEILING_SOURCE = "profiles/r03_gather_probe_peak.txt"
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4           # peak engine clock
 # a wave64 VALU instruction occupies its SIMD for one "quad-cycle" (4 clocks: 16 lanes per clock); SQ_ACTIVE_INST_VALU
@@ -131,7 +136,7 @@ def hbm_regime(device, chains, theta=THETA):
     pmc_all, pmc_why = load_traffic_json()
     pmc = {} if pmc_all is None else pmc_all.get("hbm_regime", {})
 
-    def run(name, key, h, stats, sweeps, table_bytes, rebuild_cols=0):
+    def run(name, key, h, stats, sweeps, table_bytes, rebuild_cols=0, ceil=None, ceil_source=None, pmc_entry=None):
         h.adjust_windows(200, theta)
         h.sample(sweeps, theta)
         s0 = stats()
@@ -152,14 +157,12 @@ def hbm_regime(device, chains, theta=THETA):
         # this run); `frac` = against the MEASURED gather-only ceiling of this access pattern on this table size
         # (GATHER_CEILINGS_BY_GRID); the nominal 8 TB/s HBM peak is the second key.  The counter traffic beyond L2 rides
         # along only when profiles/traffic.json was measured on the build that is running.
-        n_grid = table_bytes // 512
-        ceil = GATHER_CEILINGS_BY_GRID.get(n_grid)
-        e.update({"achieved": alg, "measured_gather_ceiling_GBps": ceil, "measured_gather_ceiling_source": GATHER_CEILING_SOURCE,
+        e.update({"achieved": alg, "measured_gather_ceiling_GBps": ceil, "measured_gather_ceiling_source": ceil_source,
                   "frac": None if ceil is None else alg / ceil, "frac_of_nominal_hbm_peak": alg / HBM_PEAK_GBS,
                   "infinity_cache_share_upper_bound": min(1.0, 256e6 / table_bytes),
-                  "frac_note": "algorithmic rate over the gather-only ceiling measured on the free sampler's own column distribution on a "
-                               "table of this size (8 B per lane, 4096 waves); sac/peak entries use the same table sizes and that ceiling"})
-        t = pmc.get(key)
+                  "frac_note": "algorithmic rate (for sac/peak including the per-sweep Gbar rebuild) over the gather-only ceiling measured on "
+                               "this sampler's own column distribution on a table of this size (8 B per lane, 4096 waves, 16 rows in flight)"})
+        t = pmc_entry if pmc_entry is not None else pmc.get(key)
         if t and sweeps == 100 and h.n_chains == 4096:
             cnt = t["bytes_per_launch"] / (kms / nl / 1e3) / 1e9
             e.update({"traffic": t["bytes_per_launch"], "counter_GBps_beyond_L2": cnt,
@@ -176,13 +179,23 @@ def hbm_regime(device, chains, theta=THETA):
         prob = FreeProblem(td, N_OMEGA, 0.0, OMEGA_M, d_omega, par=1, kernel_type="bosonic")
         h = prob.make_handle(n_chains=chains, seed=SEED, device=device, device_tables=True)
         run(f"sac/free bosonic, N_tau=64, 2000 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
-            f"{chains} chains", f"free_{prob.n_grid}", h, h.stats, 100, prob.n_grid * 512)
+            f"{chains} chains", f"free_{prob.n_grid}", h, h.stats, 100, prob.n_grid * 512,
+            ceil=GATHER_CEILINGS_BY_GRID.get(prob.n_grid), ceil_source=GATHER_CEILING_SOURCE)
     for d_omega in (1e-5, 2.5e-6):
         prob = PeakProblem(td, 1000, 1, 0.5, OMEGA_M, d_omega, kernel_type="bosonic")
         h = prob.make_handle(n_chains=chains, seed=SEED, device=device, device_tables=True)
         run(f"sac/peak bosonic, N_tau=64, 1000+1 deltas, {prob.n_grid}-column table ({prob.n_grid * 512 / 2**20:.0f} MiB), "
             f"{chains} chains" + (" (BASELINE.json configs[3])" if d_omega == 1e-5 else ""), f"peak_{prob.n_grid}", h, h.peak_stats, 100,
-            prob.n_grid * 512, rebuild_cols=1001)
+            prob.n_grid * 512, rebuild_cols=1001, ceil=PEAK_GATHER_CEILINGS.get(prob.n_grid), ceil_source=PEAK_GATHER_CEILING_SOURCE)
+    # sac/peak on both frequency axes with the weight-transfer moves (fermionic finite-T; the workload of tools/bench_param.py peak2
+    # and of its PMC passes, same seeds): two 488 MiB tables
+    t2 = synthetic_timedata(n_tau=N_TAU, seed=777, kernel_type="finiteT")
+    prob = PeakProblem(t2, 1000, 1, 0.5, OMEGA_M, 1e-5, kernel_type="finiteT", approx_ratio=2.5)
+    h = prob.make_handle(n_chains=chains, seed=777, device=device)
+    run(f"sac/peak finite-T, both axes with weight transfers, N_tau=64, 2 x (1000+1) deltas, two {prob.n_grid}-column tables (977 MiB), "
+        f"{chains} chains", "peak_two_axes", h, h.peak_stats, 100, 2 * prob.n_grid * 512, rebuild_cols=2002,
+        ceil=PEAK_GATHER_CEILINGS["two_axes_1000001"], ceil_source=PEAK_GATHER_CEILING_SOURCE,
+        pmc_entry=None if pmc_all is None else pmc_all.get("other", {}).get("peak_two_axes"))
     # BASELINE configs[2]'s kernel on one GPU: sac/edge single_edge, N_e=80, K / dK / d2K tables of 10^6+1 columns (1465 MiB),
     # one 40-sweep launch per bin (the workload of tools/bench_param.py edge and of the PMC passes, same seeds)
     from sac_amd.edge import EdgeProblem

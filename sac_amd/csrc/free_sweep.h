@@ -375,6 +375,212 @@ __device__ __forceinline__ int move_loop(Chain<NTL> &c, const int MOVE, int n_it
     return accepted;
 }
 
+// The same loop for runs in which many proposals never reach the evaluation (bounds: the peak program's continuum and
+// peak moves, peak:382-700).  move_loop's ring holds the next DEPTH proposals whatever they are, so with a fraction f of
+// them alive only f * DEPTH column pairs are really in flight and the wave waits out the memory latency (measured on the
+// two-axis peak shape: 41 % alive, 4.9 TB/s = what 6.6 rows per wave in flight give by Little's law).  Here ONLY live
+// proposals enter the ring: `pend` is the set of decoded proposals that are in bounds and not yet requested, consumed lowest
+// index first; the others cost nothing but their log record.  The chain is the sequential chain as before:
+//   * an accepted move re-decodes the later proposals that use a moved delta (as move_loop does);
+//   * those already in the ring are marked stale and refetched when resolved (as move_loop does);
+//   * those not yet requested are simply requested with their new columns, dropped if they left the bounds, added if they
+//     came into bounds -- unless such an arrival lies in FRONT of a proposal that is already in the ring, which would
+//     break the order: then the ring is started again from the proposal after the current one (rare).
+template <int NCOL, int DEPTH, int NTL, bool LOG, bool UA>
+__device__ __forceinline__ int move_loop_live(Chain<NTL> &c, const int MOVE, int n_it, double window)
+{
+    int accepted = 0, n_eval = 0;
+    for (int base = 0; base < n_it; base += 64) {
+        c.prio.rotate();
+        const int cnt = (n_it - base < 64) ? (n_it - base) : 64;
+        Decoded<NCOL, UA> d;
+        decode<NCOL, NTL, UA>(c, MOVE, (uint32_t)(base + (c.lane < cnt ? c.lane : cnt - 1)), window, d);
+        const unsigned long long in_group = (cnt == 64) ? ~0ull : ((1ull << cnt) - 1ull);
+        unsigned long long pend = __builtin_amdgcn_ballot_w64(d.inb != 0) & in_group;
+        unsigned long long inring = 0ull, stale = 0ull;
+        int last_issued = -1;
+        int hold = 0;                   // after a restart: the slot of the restarting proposal stays empty for one turn
+        int log_next = 0;               // LOG: first proposal of the group without a record
+
+        double kn[DEPTH][NCOL][NTL], ko[DEPTH][NCOL][NTL];
+        int is_j[DEPTH], is_old[DEPTH][NCOL], is_new[DEPTH][NCOL];
+
+        auto log_skipped = [&](int upto) {      // proposals log_next .. upto-1 never reached the evaluation
+            if constexpr (LOG) {
+                if (c.log != nullptr) {
+                    for (int s_ = log_next; s_ < upto; ++s_) {
+                        if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {
+                            MoveRec r;
+                            r.chi2_new = 0.0;
+                            r.flags = 0;
+                            r.move = MOVE;
+                            c.log[c.log_pos] = r;
+                        }
+                        c.log_pos += 1;
+                    }
+                }
+                log_next = upto;
+            }
+        };
+        auto issue = [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            int j = 64;
+            if (hold == 0 && pend != 0ull) {
+                j = (int)__builtin_ctzll(pend);
+                pend &= pend - 1ull;
+                inring |= 1ull << j;
+                last_issued = j;
+            }
+            hold = 0;
+            is_j[u] = j;
+            const bool live = j < 64;
+            const int jj = live ? j : 0;
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) {
+                const int o = __builtin_amdgcn_readlane(d.wold[q], jj);
+                const int nw = __builtin_amdgcn_readlane(d.wnew[q], jj);
+                is_old[u][q] = o;
+                is_new[u][q] = nw;
+                // an empty slot still issues its loads (the waits count outstanding loads statically): parked on column 0
+                load_col<NTL>(c, live ? nw : 0, kn[u][q]);
+                load_col<NTL>(c, live ? o : 0, ko[u][q]);
+            }
+        };
+        auto resolve = [&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const int j = is_j[u];
+            if (j >= 64) return;
+            inring &= ~(1ull << j);
+            log_skipped(j);
+            int inb = 1;
+            int s_old[NCOL], s_new[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) { s_old[q] = is_old[u][q]; s_new[q] = is_new[u][q]; }
+            const bool was_stale = (stale != 0ull) && (((stale >> j) & 1ull) != 0ull);
+            if (was_stale) {                 // a delta of this proposal moved while its columns were in flight
+                stale &= ~(1ull << j);
+                inb = __builtin_amdgcn_readlane(d.inb, j);
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) {
+                    s_old[q] = __builtin_amdgcn_readlane(d.wold[q], j);
+                    s_new[q] = __builtin_amdgcn_readlane(d.wnew[q], j);
+                }
+            }
+            int acc = 0;
+            double chi2_new = 0.0;
+            if (inb) {
+                double s_A[NCOL];
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) {
+                    if constexpr (UA) s_A[q] = c.A_uniform;
+                    else s_A[q] = readlane_f64(d.A[q], j);
+                }
+                double inc[NCOL][NTL];
+                if (!was_stale) {
+                    increments<NCOL, NTL>(s_A, kn[u], ko[u], inc);
+                } else {
+                    double fn[NCOL][NTL], fo[NCOL][NTL];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) {
+                        load_col<NTL>(c, s_new[q], fn[q]);
+                        load_col<NTL>(c, s_old[q], fo[q]);
+                    }
+                    increments<NCOL, NTL>(s_A, fn, fo, inc);
+                }
+                double gnew[NTL], term = 0.0;
+#pragma unroll
+                for (int t = 0; t < NTL; ++t) {
+                    double g = c.gbar[t];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) g = g + inc[q][t];
+                    gnew[t] = g;
+                    const double e = (g - c.G[t]) * c.sinv[t];        // free:259-261
+                    const double e2 = e * e;
+                    term = (t == 0) ? e2 : (term + e2);
+                }
+                const double sum63 = wave_sum_lane63(term);
+                const double ln_u = readlane_f64(d.lnu, j);
+                acc = lane63_true(metropolis(c.chi2, sum63, c.inv2theta, ln_u)) ? 1 : 0;
+                n_eval += 1;
+                if (LOG || acc) chi2_new = readlane_f64(sum63, 63);
+                if (acc) {                                            // free:310-318
+#pragma unroll
+                    for (int t = 0; t < NTL; ++t) c.gbar[t] = gnew[t];
+                    c.chi2 = chi2_new;
+                    if (chi2_new < c.chi2_min) c.chi2_min = chi2_new;
+                    int s_k[NCOL];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) s_k[q] = __builtin_amdgcn_readlane(d.k[q], j);
+                    if (c.lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < NCOL; ++q) c.wi[s_k[q]] = (uint32_t)s_new[q];
+                    }
+                    accepted += 1;
+                    bool same = false;
+#pragma unroll
+                    for (int a = 0; a < NCOL; ++a)
+#pragma unroll
+                        for (int b = 0; b < NCOL; ++b) same = same || (d.k[a] == s_k[b]);
+                    const unsigned long long above = (~0ull << j) << 1;
+                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(same) & above & in_group;
+                    if (hits != 0ull) {
+                        if ((hits >> c.lane) & 1ull) {
+#pragma unroll
+                            for (int q = 0; q < NCOL; ++q) d.wold[q] = (int)c.wi[d.k[q]];
+                            compute_new<NCOL, UA>(d, c.lo, c.hi);
+                        }
+                        stale |= hits & inring;
+                        const unsigned long long now = __builtin_amdgcn_ballot_w64(d.inb != 0) & above & in_group;
+                        const unsigned long long fresh = now & ~inring;
+                        const unsigned long long arrivals = fresh & ~pend;
+                        if (arrivals != 0ull && (int)__builtin_ctzll(arrivals) < last_issued) {
+                            // a proposal came into bounds in front of one whose columns are already requested: start again
+                            pend = now;
+                            inring = 0ull;
+                            stale = 0ull;
+                            last_issued = j;
+                            hold = 1;
+#pragma unroll
+                            for (int v = 0; v < DEPTH; ++v) is_j[v] = 64;
+                        } else {
+                            pend = fresh;
+                        }
+                    }
+                }
+            }
+            if constexpr (LOG) {
+                if (c.log != nullptr) {
+                    if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {
+                        MoveRec r;
+                        r.chi2_new = inb ? chi2_new : 0.0;
+                        r.flags = (inb ? 1 : 0) | (acc ? 2 : 0);
+                        r.move = MOVE;
+                        c.log[c.log_pos] = r;
+                    }
+                    c.log_pos += 1;
+                }
+                log_next = j + 1;
+            }
+        };
+
+        [&]<int... Us>(std::integer_sequence<int, Us...>) {
+            (issue(std::integral_constant<int, Us>{}), ...);
+        }(std::make_integer_sequence<int, DEPTH>{});
+        while (true) {
+            [&]<int... Us>(std::integer_sequence<int, Us...>) {
+                ((resolve(std::integral_constant<int, Us>{}), issue(std::integral_constant<int, Us>{})), ...);
+            }(std::make_integer_sequence<int, DEPTH>{});
+            if (pend == 0ull && inring == 0ull) break;
+        }
+        log_skipped(cnt);
+    }
+    c.n_eval += (uint32_t)n_eval;
+    c.n_cols += (uint32_t)n_eval * (uint32_t)(2 * NCOL);
+    c.n_acc += (uint32_t)accepted;
+    c.n_accmoves += (uint32_t)accepted * (uint32_t)NCOL;
+    return accepted;
+}
+
 // ------------------------------------------------------------------------------------------
 // par = 2 amplitude moves (free:483-570 A_w_move, free:674-728 double_A_move).  The chain's
 // amplitudes live in LDS (c.A points there) because they change during the launch.

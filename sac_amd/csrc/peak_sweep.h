@@ -72,16 +72,17 @@ __device__ __forceinline__ void peak_refresh_gbar(Chain<NTL> &c, const char *Kp,
         for (int t = 0; t < NTL; ++t) acc[t] = 0.0;
         const int f = first[grp], n = count[grp];
         int i = 0;
-        for (; i + 8 <= n; i += 8) {                 // eight columns in flight
-            double col[8][NTL], a[8];
+        constexpr int B = 8;                         // columns in flight (16 was measured: slower, at full occupancy and for a lone chain)
+        for (; i + B <= n; i += B) {
+            double col[B][NTL], a[B];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < B; ++u) {
                 const int w = __builtin_amdgcn_readfirstlane((int)c.wi[f + i + u]);
                 load_col<NTL>(c, w, col[u]);
                 a[u] = A[f + i + u];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < B; ++u)
 #pragma unroll
                 for (int t = 0; t < NTL; ++t) acc[t] = acc[t] + col[u][t] * a[u];
         }
@@ -195,33 +196,65 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
             for (int e = 0; e < NE; ++e) { d.wold[e] = (int)c.wi[d.k[e]]; d.A[e] = A[d.k[e]]; }
             xfer_compute<NPAIR>(d, sp);
         }
+        // only proposals that reach the evaluation enter the prefetch ring (see move_loop_live in free_sweep.h)
+        const unsigned long long in_group = (cnt == 64) ? ~0ull : ((1ull << cnt) - 1ull);
+        unsigned long long pend = __builtin_amdgcn_ballot_w64(d.inb != 0) & in_group;
+        unsigned long long inring = 0ull, stale = 0ull;
+        int last_issued = -1, hold = 0, log_next = 0;
         double kn[DEPTH][NE][NTL], ko[DEPTH][NE][NTL];
-        int is_inb[DEPTH], is_old[DEPTH][NE], is_new[DEPTH][NE];
-        unsigned long long stale = 0ull;
+        int is_j[DEPTH], is_old[DEPTH][NE], is_new[DEPTH][NE];
 
         auto fetch = [&](int e, int col, double (&out)[NTL]) {
             c.Kb = (e & 1) ? Kn : Kp;
             load_col<NTL>(c, col, out);
         };
-        auto issue = [&](auto U, int j) {
+        auto log_skipped = [&](int upto) {
+            if constexpr (LOG) {
+                if (c.log != nullptr) {
+                    for (int s_ = log_next; s_ < upto; ++s_) {
+                        if (c.lane == 0 && (long long)c.log_pos < c.log_cap) {
+                            MoveRec r;
+                            r.chi2_new = 0.0;
+                            r.flags = 0;
+                            r.move = sp.move_id;
+                            c.log[c.log_pos] = r;
+                        }
+                        c.log_pos += 1;
+                    }
+                }
+                log_next = upto;
+            }
+        };
+        auto issue = [&](auto U) {
             constexpr int u = decltype(U)::value;
-            const int jj = (j < cnt) ? j : cnt - 1;
-            const int inb = __builtin_amdgcn_readlane(d.inb, jj);
-            is_inb[u] = inb;
+            int j = 64;
+            if (hold == 0 && pend != 0ull) {
+                j = (int)__builtin_ctzll(pend);
+                pend &= pend - 1ull;
+                inring |= 1ull << j;
+                last_issued = j;
+            }
+            hold = 0;
+            is_j[u] = j;
+            const bool live = j < 64;
+            const int jj = live ? j : 0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const int o = __builtin_amdgcn_readlane(d.wold[e], jj);
-                const int nw = inb ? __builtin_amdgcn_readlane(d.wnew[e], jj) : o;
+                const int nw = __builtin_amdgcn_readlane(d.wnew[e], jj);
                 is_old[u][e] = o;
                 is_new[u][e] = nw;
-                const bool live = inb && (j < cnt);       // never evaluated otherwise: park the loads on column 0 (free_sweep.h)
-                fetch(e, live ? nw : 0, kn[u][e]);
+                fetch(e, live ? nw : 0, kn[u][e]);        // empty slot: parked on column 0
                 fetch(e, live ? o : 0, ko[u][e]);
             }
         };
-        auto resolve = [&](auto U, int j) {
+        auto resolve = [&](auto U) {
             constexpr int u = decltype(U)::value;
-            int inb = is_inb[u];
+            const int j = is_j[u];
+            if (j >= 64) return;
+            inring &= ~(1ull << j);
+            log_skipped(j);
+            int inb = 1;
             int s_old[NE], s_new[NE];
 #pragma unroll
             for (int e = 0; e < NE; ++e) { s_old[e] = is_old[u][e]; s_new[e] = is_new[u][e]; }
@@ -296,14 +329,28 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
                     bool hit = false;
 #pragma unroll
                     for (int e = 0; e < NE; ++e) hit = hit || (d.k[e] == s_k[e]);   // groups are disjoint
-                    hit = hit && (c.lane > j);
-                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit);
+                    const unsigned long long above = (~0ull << j) << 1;
+                    const unsigned long long hits = __builtin_amdgcn_ballot_w64(hit) & above & in_group;
                     if (hits != 0ull) {
-                        stale |= hits & ((((1ull << DEPTH) - 2ull)) << j);   // columns in flight: j+1 .. j+DEPTH-1
-                        if (hit) {
+                        if ((hits >> c.lane) & 1ull) {
 #pragma unroll
                             for (int e = 0; e < NE; ++e) { d.wold[e] = (int)c.wi[d.k[e]]; d.A[e] = A[d.k[e]]; }
                             xfer_compute<NPAIR>(d, sp);
+                        }
+                        stale |= hits & inring;                               // columns in flight: refetched when resolved
+                        const unsigned long long now = __builtin_amdgcn_ballot_w64(d.inb != 0) & above & in_group;
+                        const unsigned long long fresh = now & ~inring;
+                        const unsigned long long arrivals = fresh & ~pend;
+                        if (arrivals != 0ull && (int)__builtin_ctzll(arrivals) < last_issued) {
+                            pend = now;                                       // start the ring again behind proposal j (rare)
+                            inring = 0ull;
+                            stale = 0ull;
+                            last_issued = j;
+                            hold = 1;
+#pragma unroll
+                            for (int v = 0; v < DEPTH; ++v) is_j[v] = 64;
+                        } else {
+                            pend = fresh;
                         }
                     }
                 }
@@ -319,17 +366,19 @@ __device__ __forceinline__ int xfer_loop(Chain<NTL> &c, const char *Kp, const ch
                     }
                     c.log_pos += 1;
                 }
+                log_next = j + 1;
             }
         };
         [&]<int... Us>(std::integer_sequence<int, Us...>) {
-            (issue(std::integral_constant<int, Us>{}, Us), ...);
+            (issue(std::integral_constant<int, Us>{}), ...);
         }(std::make_integer_sequence<int, DEPTH>{});
-        for (int j0 = 0; j0 < cnt; j0 += DEPTH) {
+        while (true) {
             [&]<int... Us>(std::integer_sequence<int, Us...>) {
-                (((j0 + Us < cnt) ? (resolve(std::integral_constant<int, Us>{}, j0 + Us), 0) : 0,
-                  issue(std::integral_constant<int, Us>{}, j0 + Us + DEPTH)), ...);
+                ((resolve(std::integral_constant<int, Us>{}), issue(std::integral_constant<int, Us>{})), ...);
             }(std::make_integer_sequence<int, DEPTH>{});
+            if (pend == 0ull && inring == 0ull) break;
         }
+        log_skipped(cnt);
     }
     c.Kb = keep;
     return accepted;

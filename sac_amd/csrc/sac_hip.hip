@@ -319,7 +319,10 @@ peak_stage_kernel(const PeakParams pp)
         b_pp = group_max(c.wi, f_pp, n_p, lane);
         if (pp.sample_neg) b_np = group_max(c.wi, f_pn, n_p, lane);
     }
-    constexpr int D1 = (NTL == 1) ? 8 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
+#ifndef PEAK_D1
+#define PEAK_D1 8
+#endif
+    constexpr int D1 = (NTL == 1) ? PEAK_D1 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
     for (int s = 0; s < p.n_sweeps; ++s) {
         c.sweep_lo = (uint32_t)sweep;
         c.sweep_hi = (uint32_t)(sweep >> 32) & 0xFFFFu;
@@ -382,13 +385,13 @@ peak_stage_kernel(const PeakParams pp)
             c.lo = ((pn == 1) ? b_pp : b_np) + 1;                    // new <= floor(w_b): continue (peak:409)
             c.hi = wim;
             PEAK_TICK(9);
-            a = move_loop<1, D1, NTL, LOG, false>(c, 11 + pn - 1, n, win[0 + o7]);
+            a = move_loop_live<1, D1, NTL, LOG, false>(c, 11 + pn - 1, n, win[0 + o7]);
             if (lane == 0) acc[0 + o7] += (double)a / (double)n;
             PEAK_TICK(4);
-            a = move_loop<2, D2, NTL, LOG, false>(c, 13 + pn - 1, n / 2, win[1 + o7]);
+            a = move_loop_live<2, D2, NTL, LOG, false>(c, 13 + pn - 1, n / 2, win[1 + o7]);
             if (lane == 0) acc[1 + o7] += (double)(2 * a) / (double)(n / 2);
             PEAK_TICK(5);
-            a = move_loop<3, D3, NTL, LOG, false>(c, 15 + pn - 1, n / 3, 0.0);
+            a = move_loop_live<3, D3, NTL, LOG, false>(c, 15 + pn - 1, n / 3, 0.0);
             if (lane == 0) acc[2 + o7] += (double)a / (double)(n / 3);
             PEAK_TICK(6);
             n_prop += n + n / 2 + n / 3;
@@ -402,7 +405,7 @@ peak_stage_kernel(const PeakParams pp)
                 c.k_count = n_p;
                 c.lo = wi0;                                          // peak:659-663
                 c.hi = (pn == 1) ? b_pc : b_nc;
-                a = move_loop<1, D1, NTL, LOG, false>(c, 17 + pn - 1, 10 * n_p, win[pn == 1 ? 3 : 4]);
+                a = move_loop_live<1, D1, NTL, LOG, false>(c, 17 + pn - 1, 10 * n_p, win[pn == 1 ? 3 : 4]);
                 if (lane == 0) acc[pn == 1 ? 3 : 4] += (double)a / (double)(10 * n_p);
                 n_prop += 10 * n_p;
                 const int m = group_max(c.wi, c.k_first, n_p, lane); // peak:693-697

@@ -18,6 +18,10 @@ CASES = [
                                    n_p=3, omega_m=8.0, d_omega=1e-3), True, 10.0, 10, 6, 3),
     ("zeroT_ntau80_fixedge", dict(kind="synth", kernel_type="zeroT", approx_ratio=np.inf, n_tau=80, n_omega=200,
                                   n_p=1, omega_m=8.0, d_omega=1e-3, fix_edge=1, omega_0=0.4), False, 5.0, 10, 6, 3),
+    # a dozen deltas per group: nearly every accepted move touches a delta of a later, already decoded proposal of the same group of
+    # 64 (re-decodes, stale ring entries, proposals entering and leaving the bounds, ring restarts of the live-proposal loops)
+    ("both_axes_tiny_n12", dict(kind="golden", kernel_type="finiteT", approx_ratio=1.7, n_omega=12, n_p=2), True, 20.0, 60, 40, 10),
+    ("bosonic_tiny_n9_cold", dict(kind="golden", kernel_type="bosonic", n_omega=9, n_p=1), False, 0.5, 60, 40, 10),
     # the limits of the handle: N_omega = SAC_MAX_N_OMEGA = 2048 continuum deltas per axis (+ 11 peak deltas), both axes, N_tau = 128
     ("max_state_both_axes_ntau128", dict(kind="synth", kernel_type="finiteT", approx_ratio=2.0, n_tau=128, n_omega=2048,
                                          n_p=11, omega_m=8.0, d_omega=1e-3), True, 10.0, 10, 2, 1),

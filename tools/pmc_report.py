@@ -53,7 +53,7 @@ def per_dispatch(path, want):
 
 
 def main():
-    print("rocprofv3 --pmc passes on the committed library (scripts/r02_pmc.sh; one counter set per run).")
+    print("rocprofv3 --pmc passes on the committed library (scripts/r03_pmc.sh; one counter set per run).")
     print("Values are per dispatch, summed over XCDs/instances.  FETCH_SIZE/WRITE_SIZE in KB; FETCH_SIZE counts half the")
     print("bytes on gfx950 (MI355X_MICROARCH.md), hence (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes beyond L2.")
     traffic, free_use = {}, None
@@ -105,7 +105,7 @@ def main():
         use = free_use
         src = [a for a in sys.argv[1:] if a.startswith("--source=")]
         source = src[0].split("=", 1)[1] if src else "profiles/r02_pmc_summary.txt"
-        json.dump({"_comment": "HBM/fabric-side traffic per launch from rocprofv3 --pmc (separate passes; scripts/r02_pmc.sh, summary in 'source'), "
+        json.dump({"_comment": "HBM/fabric-side traffic per launch from rocprofv3 --pmc (separate passes; scripts/r03_pmc.sh, summary in 'source'), "
                                "for bench.py's roofline.traffic and hbm_regime[].traffic. bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE counts "
                                "half the bytes on gfx950, calibrated on this access pattern in profiles/r01_gather_probe.txt. "
                                "valu_active_quad_cycles = SQ_ACTIVE_INST_VALU (quad-cycles a SIMD's vector ALU was busy), for roofline.bound = valu-issue.",
