@@ -43,7 +43,7 @@ GATHER_CEILING_SOURCE = "profiles/r03_gather_probe.txt"
 # the same probe on the sac/peak samplers' column distributions (tools/dump_positions_peak.py; the continuum deltas of a peak run
 # crowd behind the peak: fewer distinct columns per chain, hence higher ceilings than sac/free's on the same table size);
 # "two" = both axes, the two 488 MiB tables as one 976.6 MiB footprint
-PEAK_GATHER_CEILINGS = {1000001: 11607.4, 4000001: None, "two_axes_1000001": 12543.0}
+PEAK_GATHER_CEILINGS = {1000001: 11607.4, 4000001: 8077.6, "two_axes_1000001": 12543.0}
 PEAK_GATHER_CEILING_SOURCE = "profiles/r03_gather_probe_peak.txt"
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4           # peak engine clock

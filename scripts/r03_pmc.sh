@@ -24,13 +24,18 @@ PKH4="$R/tools/bench_param.py peak_hbm --d-omega 2.5e-6"
 HBM1="$R/tools/bench_param.py free_hbm --d-omega 1e-5"
 HBM4="$R/tools/bench_param.py free_hbm --d-omega 2.5e-6"
 PACK="$R/tools/bench_param.py free_packed"
+PART=${1:-all}
+if [ "$PART" = "a" ] || [ "$PART" = "all" ]; then
 run free_p1 "$P1" $FREE && run free_p3 "$P3" $FREE && run free_p4 "$P4" $FREE && run free_p2 "$P2" $FREE && \
 run hbm1_p3 "$P3" $HBM1 && run hbm1_p4 "$P4" $HBM1 && run hbm4_p3 "$P3" $HBM4 && run hbm4_p4 "$P4" $HBM4 && \
 run pk2_p1 "$P1" $PEAK2 && run pk2_p3 "$P3" $PEAK2 && run pk2_p4 "$P4" $PEAK2 && \
-run pkhb_p3 "$P3" $PKHB && run pkhb_p4 "$P4" $PKHB && run pkh4_p3 "$P3" $PKH4 && run pkh4_p4 "$P4" $PKH4 && \
+run pkhb_p3 "$P3" $PKHB && run pkhb_p4 "$P4" $PKHB && run pkh4_p3 "$P3" $PKH4 && run pkh4_p4 "$P4" $PKH4 || exit 1
+fi
+if [ "$PART" = "b" ] || [ "$PART" = "all" ]; then
 run peak_p1 "$P1" $PEAK && run peak_p3 "$P3" $PEAK && run peak_p4 "$P4" $PEAK && run peak_p2 "$P2" $PEAK && \
 run edge_p1 "$P1" $EDGE && run edge_p3 "$P3" $EDGE && run edge_p4 "$P4" $EDGE && run edge_p2 "$P2" $EDGE && \
-run pack_p1 "$P1" $PACK && run pack_p3 "$P3" $PACK && run pack_p4 "$P4" $PACK && run pack_p2 "$P2" $PACK
+run pack_p1 "$P1" $PACK && run pack_p3 "$P3" $PACK && run pack_p4 "$P4" $PACK && run pack_p2 "$P2" $PACK || exit 1
+fi
 # keep the pulled set small: only the counter tables
 find $O -name "*agent_info.csv" -delete
 du -sh $O
