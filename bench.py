@@ -346,9 +346,23 @@ def main():
     # handle's stream); torch only carries the 128-byte unique id to the ranks.  The rehearsal (ranks sharing a GPU) cannot
     # open an RCCL communicator and keeps the host-side merge below.
     abi_merge = dist_on and not rehearse
+    abi_error = None
     if abi_merge:
         from sac_amd.dist import Comm
-        Comm(device=torch.device("cuda", local_rank)).attach(h)
+        try:
+            Comm(device=torch.device("cuda", local_rank)).attach(h)
+        except Exception as ex:              # e.g. librccl not loadable: the same on every rank
+            abi_error = str(ex)
+        # all ranks take the same path: if the communicator did not come up everywhere, the per-stage merge stays with
+        # torch.distributed (RCCL all-reduces on device buffers, below) and the output line says so
+        ok = torch.tensor([0.0 if abi_error else 1.0], dtype=torch.float64, device="cuda")
+        all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.cpu()[0]) < 0.5:
+            abi_merge = False
+            abi_error = abi_error or "sac_comm_init failed on another rank"
+    if abi_merge:
+        h.adjust_windows(100, theta)         # one more untimed tuning round: from here on h.stats() is the merged view
+                                             # (counters summed over ALL ranks' chains), before and after the timed region
 
     def step():
         h.sample(args.sweeps_per_step, theta)
@@ -388,9 +402,12 @@ def main():
     if dist_on:
         tmax = local[:1].clone()
         all_reduce(tmax, op=dist.ReduceOp.MAX)
-        all_reduce(local)
+        if not abi_merge:
+            all_reduce(local)                # behind the ABI the handle's counters already are the sums over all ranks
         local[0] = tmax[0]
     dt_max, moves, props, sweeps, cols, evald = (float(x) for x in local.cpu())
+    # this rank's share of the counters (weak scaling: every rank runs the same number of chains and sweeps)
+    per_rank = 1.0 / world if abi_merge else 1.0
 
     if rank == 0:
         # Roofline of the dominant kernel (free_stage_kernel), this rank, measured with HIP events on the library's
@@ -398,8 +415,9 @@ def main():
         # resident (TCC hit 2/3), so HBM does not bind it: the binding resource is VALU issue on the SIMDs (PMC:
         # SQ_ACTIVE_INST_VALU, profiles/traffic.json).  bound/achieved/peak/frac are stated against that ceiling; the
         # algorithmic gather rate and the counter-based HBM fraction are extra keys.
-        cols_r0 = s1.columns_gathered - s0.columns_gathered
-        sweeps_r0 = s1.sweeps - s0.sweeps
+        cols_r0 = (s1.columns_gathered - s0.columns_gathered) * per_rank
+        sweeps_r0 = (s1.sweeps - s0.sweeps) * per_rank
+        props_r0 = (s1.proposals - s0.proposals) * per_rank
         n_l = max(launches, 1)
         alg_bytes = cols_r0 * N_TAU * 8 + sweeps_r0 * N_OMEGA * 16   # K columns + histogram RMW
         per_launch_s = kernel_ms / 1e3 / n_l
@@ -425,8 +443,8 @@ def main():
             roof = {"bound": "valu-issue", "achieved": ach, "peak": VALU_ISSUE_PEAK,
                     "unit": "G wave64 VALU issue quad-cycles/s (peak = 1024 SIMDs x 2.4 GHz / 4)",
                     "frac": ach / VALU_ISSUE_PEAK,
-                    "valu_insts_per_proposal": pmc["valu_insts_median"] * scale / ((s1.proposals - s0.proposals) / n_l),
-                    "salu_insts_per_proposal": pmc["salu_insts_median"] * scale / ((s1.proposals - s0.proposals) / n_l)}
+                    "valu_insts_per_proposal": pmc["valu_insts_median"] * scale / (props_r0 / n_l),
+                    "salu_insts_per_proposal": pmc["salu_insts_median"] * scale / (props_r0 / n_l)}
         else:
             roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_ISSUE_PEAK,
                     "unit": "G wave64 VALU issue quad-cycles/s", "frac": None, "achieved_null_reason": pmc_why}
@@ -459,7 +477,8 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "chains_per_gpu": args.chains, "sweeps_per_step": args.sweeps_per_step,
                        "theta": theta, "parallelism": f"chains sharded over {world} GPU(s), "
-                                                      "one fused RCCL all-reduce(sum) + one all-reduce(min) per stage behind the C ABI"},
+                                                      ("one fused RCCL all-reduce(sum) + one all-reduce(min) per stage behind the C ABI"
+                                                       if (abi_merge or not dist_on) else "per-stage RCCL all-reduces through torch.distributed")},
             "sweeps_per_s": sweeps / dt_max, "proposals_per_s": props / dt_max,
             "acceptance": {"evaluated_frac": evald / props, "accepted_moves_per_proposal": moves / props},
             "roofline": roof,
@@ -477,6 +496,8 @@ def main():
             out["speedup_note"] = f"one MI355X against {cb['cores']} host cores running the CPU port concurrently"
         if abi_merge:
             out["merge"] = dict(h_comm_info, where="behind the C ABI (sac_comm_init)")
+        elif abi_error:
+            out["merge"] = {"where": "torch.distributed all-reduces (fallback)", "sac_comm_init_error": abi_error}
         if dist_on and world == 1:
             out["collectives"] = "forced on with one rank (SAC_BENCH_FORCE_DIST=1): RCCL communicator, per-stage all-reduces and barrier executed"
         print(json.dumps(out))
