@@ -476,7 +476,7 @@ def main():
                                    f"{prob.n_grid}-point omega grid, {args.chains} chains per MI355X, Theta={theta:g} "
                                    "(BASELINE.json configs[1])",
                        "chains_per_gpu": args.chains, "sweeps_per_step": args.sweeps_per_step,
-                       "theta": theta, "parallelism": f"chains sharded over {world} GPU(s), "
+                       "theta": theta, "parallelism": f"chains sharded over {world} GPU(s), " +
                                                       ("one fused RCCL all-reduce(sum) + one all-reduce(min) per stage behind the C ABI"
                                                        if (abi_merge or not dist_on) else "per-stage RCCL all-reduces through torch.distributed")},
             "sweeps_per_s": sweeps / dt_max, "proposals_per_s": props / dt_max,

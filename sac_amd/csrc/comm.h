@@ -33,6 +33,7 @@ struct Api {
     const char *(*GetErrorString)(int) = nullptr;
     void *lib = nullptr;
     char why[256] = "";
+    char path[1024] = "";     // what was loaded
 };
 
 inline Api &api()
@@ -40,12 +41,26 @@ inline Api &api()
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
+        // The RCCL that belongs to the HIP runtime THIS library runs on: the handle's stream and the merge buffers are
+        // objects of that runtime, and a process may hold a second one (PyTorch ships its own libamdhip64 + librccl, whose
+        // soname is also librccl.so.1 -- asking for the bare soname would return that copy and hand it a foreign stream).
+        // So: SAC_RCCL_LIB, then librccl.so.1 next to the libamdhip64 this library is linked against, then the usual names.
+        // RTLD_LOCAL | RTLD_DEEPBIND: the copy binds to its own dependencies, whatever else is loaded.
         const char *env = std::getenv("SAC_RCCL_LIB");
-        const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        char sibling[1024] = "";
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            const char *slash = std::strrchr(info.dli_fname, '/');
+            if (slash && (size_t)(slash - info.dli_fname) + 16 < sizeof(sibling)) {
+                std::memcpy(sibling, info.dli_fname, (size_t)(slash - info.dli_fname) + 1);
+                std::strcat(sibling, "librccl.so.1");
+            }
+        }
+        const char *names[] = {env, sibling, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
         for (const char *n : names) {
             if (!n || !*n) continue;
-            a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (a.lib) break;
+            a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+            if (a.lib) { std::snprintf(a.path, sizeof(a.path), "%s", n); break; }
             std::snprintf(a.why, sizeof(a.why), "%s", dlerror());
         }
         if (!a.lib) return;
