@@ -495,7 +495,10 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
             out["speedup_note"] = f"one MI355X against {cb['cores']} host cores running the CPU port concurrently"
         if abi_merge:
-            out["merge"] = dict(h_comm_info, where="behind the C ABI (sac_comm_init)")
+            out["merge"] = dict(h_comm_info, where="behind the C ABI (sac_comm_init)", n_chains_total=int(s1.n_chains_total),
+                                n_chains_expected=world * args.chains)
+            if int(s1.n_chains_total) != world * args.chains:
+                out["merge"]["warning"] = "the merged chain count is not world x chains: the counters of this line are suspect"
         elif abi_error:
             out["merge"] = {"where": "torch.distributed all-reduces (fallback)", "sac_comm_init_error": abi_error}
         if dist_on and world == 1:
