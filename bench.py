@@ -453,6 +453,9 @@ def main():
                      "hbm_frac": None if traffic is None else traffic / per_launch_s / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_GBps": alg_gbps, "algorithmic_over_hbm_peak": alg_gbps / HBM_PEAK_GBS,
                      "gather_ceiling_GBps": GATHER_CEILING_GBS, "algorithmic_over_gather_ceiling": alg_gbps / GATHER_CEILING_GBS,
+                     # round 2's run of the same probe read 17.37 TB/s (profiles/r02_gather_probe.txt); round 3's runs read
+                     # 16.47 - 16.62 on three settings of the rows in flight: both are kept, the stricter reading is this one
+                     "algorithmic_over_gather_ceiling_round2_probe": alg_gbps / 17368.0,
                      "gather_ceiling_source": GATHER_CEILING_SOURCE + " (gather-only probe on the sampler's own column distribution, "
                                               "48.8 MiB table, 8 B per lane as the kernel loads; 16 B per lane / two rows per load: 18.8 TB/s)",
                      # instruction-independent cross-check of the counter file: every gathered column is one wave load
