@@ -24,6 +24,8 @@ clean:
 
 .PHONY: all oracle clean asm
 
-probe: tools/gather_probe
+probe: tools/gather_probe tools/lone_wave_probe
+tools/lone_wave_probe: tools/lone_wave_probe.hip
+	$(HIPCC) -O3 --offload-arch=gfx950 -Wno-unused-result -o $@ $<
 tools/gather_probe: tools/gather_probe.hip
 	$(HIPCC) -O3 --offload-arch=gfx950 -o $@ $<

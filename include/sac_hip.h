@@ -241,17 +241,6 @@ int sac_get_chains_per_wave(sac_handle_t *h, int32_t *last_used);
 int sac_set_proposals_per_step(sac_handle_t *h, int32_t proposals_per_step);
 int sac_get_proposals_per_step(sac_handle_t *h, int32_t *last_used);
 
-/* Second scheduling knob for runs with few chains (no counterpart in the reference, as above): resolve the proposals of a
- * chain two at a time as a HYPOTHESIS PAIR (free_sweep_hyp.h).  For consecutive proposals a, b the wavefront evaluates
- * chi2(a), chi2(b | a rejected) and chi2(b | a accepted) as three independent instruction streams and commits a, then b under
- * the outcome of a -- nothing is thrown away, whatever the acceptance rate, and the chain is the sequential one, bit for bit
- * (move log included).  mode: 0 = the library chooses, 1 = on, -1 = off.  Takes precedence over sac_set_proposals_per_step
- * when on; a handle that packs several chains per wave does not use it.  Equal fixed amplitudes (par = 1) for
- * SAC_KIND_FREE; SAC_KIND_PEAK handles use it in their continuum and peak move loops.  sac_get_hypothesis_pairs reports
- * whether the last sweep launch used it (1) or not (0). */
-int sac_set_hypothesis_pairs(sac_handle_t *h, int32_t mode);
-int sac_get_hypothesis_pairs(sac_handle_t *h, int32_t *last_used);
-
 /* Cross-validation scoring behind the boundary: what calc_cv.jl:29-58 computes from a GSAC.csv row
  * (cross_val.jl:105-108), taken directly from the Gbar the chains hold -- no file round trip:
  *   t = U_this Gbar (cv:106), y = U_other^T t (calc_cv.jl:37), chi2_v = sum_j ((y_j - G_other_j) sigma_inv_other_j)^2.

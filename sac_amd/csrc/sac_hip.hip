@@ -18,7 +18,6 @@
 #include "hist_sort.h"
 #include "free_sweep_packed.h"
 #include "free_sweep_spec.h"
-#include "free_sweep_hyp.h"
 #include "peak_sweep.h"
 #include "table_build.h"
 #include "cv_score.h"
@@ -35,9 +34,9 @@ using namespace sacdev;
 // per-sweep sampling work (free:918-919) and the end-of-round window retune (free:883-895).
 // PAR2 (amplitude updates, free:839-855): the amplitudes are read and written in place in global memory
 // (16 KB per chain, L2 resident), the positions stay in LDS.
-// HYP: the move loops resolve their proposals as hypothesis pairs (free_sweep_hyp.h; runs with few chains).
-template <int NTL, bool LOG, bool UA, bool PAR2, bool HYP>
-__device__ __forceinline__ void free_stage_body(const FreeParams &p)
+template <int NTL, bool LOG, bool UA, bool PAR2>
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4)
+free_stage_kernel(const FreeParams p)
 {
     constexpr int WPB = WAVES_PER_BLOCK;
     __shared__ uint32_t s_wi[WPB][MAX_N_OMEGA];
@@ -106,14 +105,11 @@ __device__ __forceinline__ void free_stage_body(const FreeParams &p)
         int a;
         // prefetch depth per move type: two tau slots per lane double the ring's registers
         constexpr int D1 = (NTL == 1) ? 8 : 4, D2 = (NTL == 1) ? 4 : 2, D3 = (NTL == 1) ? 4 : 2;
-        if constexpr (HYP) a = move_loop_hyp<1, D1, NTL, LOG, UA>(c, 1, n, win[0]);
-        else a = move_loop<1, D1, NTL, LOG, UA>(c, 1, n, win[0]);   // free:829-830
+        a = move_loop<1, D1, NTL, LOG, UA>(c, 1, n, win[0]);        // free:829-830
         if (lane == 0) acc[0] += (double)a / (double)n;
-        if constexpr (HYP) a = move_loop_hyp<2, D2, NTL, LOG, UA>(c, 2, n / 2, win[1]);
-        else a = move_loop<2, D2, NTL, LOG, UA>(c, 2, n / 2, win[1]);   // free:832-833
+        a = move_loop<2, D2, NTL, LOG, UA>(c, 2, n / 2, win[1]);    // free:832-833
         if (lane == 0) acc[1] += (double)(2 * a) / (double)(n / 2);
-        if constexpr (HYP) a = move_loop_hyp<3, D3, NTL, LOG, UA>(c, 3, n / 3, 0.0);
-        else a = move_loop<3, D3, NTL, LOG, UA>(c, 3, n / 3, 0.0);  // free:835-836
+        a = move_loop<3, D3, NTL, LOG, UA>(c, 3, n / 3, 0.0);       // free:835-836
         if (lane == 0) acc[2] += (double)a / (double)(n / 3);
         if constexpr (PAR2) {
             double *A = A_g;
@@ -126,13 +122,12 @@ __device__ __forceinline__ void free_stage_body(const FreeParams &p)
         }
         if (p.flags & STAGE_SAMPLE) {
             if (p.hist_mode == SAC_HIST_REFERENCE) {
-                // (the tag keeps the two kernel families' copies of the out-of-line sort apart: hist_sort.h)
                 if (p.n_grid < (1ll << 21))
-                    hist_reference<uint32_t, 32, HYP ? 100 : 0>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
-                                                                p.hist_exclusive, lane);
+                    hist_reference<uint32_t, 32>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
+                                                 p.hist_exclusive, lane);
                 else
-                    hist_reference<uint64_t, 32, HYP ? 100 : 0>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
-                                                                p.hist_exclusive, lane);
+                    hist_reference<uint64_t, 32>(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist,
+                                                 p.hist_exclusive, lane);
             } else {
                 hist_accumulate(c.wi, n, c.A, c.A_uniform, UA ? 1 : 0, hist, lane);
             }
@@ -175,22 +170,6 @@ __device__ __forceinline__ void free_stage_body(const FreeParams &p)
             if (c.log != nullptr) *p.log_len = c.log_pos;
         }
     }
-}
-
-template <int NTL, bool LOG, bool UA, bool PAR2>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 4)
-free_stage_kernel(const FreeParams p)
-{
-    free_stage_body<NTL, LOG, UA, PAR2, false>(p);
-}
-
-// The same stage for runs with few chains (equal fixed amplitudes): hypothesis pairs, one wave per SIMD -- the register
-// budget of four resident waves does not apply, the latency of one chain is what counts.
-template <int NTL, bool LOG>
-__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK, 1)
-free_stage_hyp_kernel(const FreeParams p)
-{
-    free_stage_body<NTL, LOG, true, false, true>(p);
 }
 
 // Gbar = K[:, idx] * A per chain, summed sequentially over the deltas (no fma), then chi^2 in
@@ -847,8 +826,6 @@ struct sac_handle {
     int last_chains_per_wave = 1;  // what the last sweep launch used
     int proposals_per_step = 0;    // sac_set_proposals_per_step: 0 = the library chooses
     int last_proposals_per_step = 1;
-    int hyp_pairs = 0;             // sac_set_hypothesis_pairs: 0 = the library chooses, 1 = on, -1 = off
-    int last_hyp_pairs = 0;        // whether the last sweep launch resolved its proposals as hypothesis pairs
     double *dK = nullptr, *dG = nullptr, *dSinv = nullptr, *dA = nullptr, *dGbar = nullptr;
     double *dHist = nullptr;
     uint32_t *dWi = nullptr;
@@ -1413,13 +1390,6 @@ static int spec_proposals_per_step(const sac_handle *h)
     return want;
 }
 
-// Hypothesis pairs (free_sweep_hyp.h, sac_set_hypothesis_pairs): the caller's choice; automatic = off for now.
-static bool hyp_pairs_wanted(const sac_handle *h)
-{
-    if (h->hyp_pairs != 0) return h->hyp_pairs > 0;
-    return false;
-}
-
 // Launches `n_sweeps` sweeps in chunks; flags_first apply to the first chunk only (zeroing),
 // flags_last to the last chunk only (retune), flags_all to every chunk.
 static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_all, int flags_first,
@@ -1481,26 +1451,6 @@ static int run_sweeps(sac_handle *h, int64_t n_sweeps, double theta, int flags_a
             }
 #undef SAC_PK
 #undef SAC_PK1
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
-            h->last_launches += 1;
-            done += chunk;
-            first = false;
-            continue;
-        }
-        h->last_hyp_pairs = 0;
-        if (ua && hyp_pairs_wanted(h)) {
-            // few chains: one chain per wave, proposals resolved as hypothesis pairs (free_sweep_hyp.h)
-            h->last_proposals_per_step = 2;
-            h->last_hyp_pairs = 1;
-            const dim3 hgrid((unsigned)((h->cfg.n_chains + wpb - 1) / wpb)), hblock(64 * wpb);
-            if (h->cfg.n_tau <= 64) {
-                if (log) hipLaunchKernelGGL((free_stage_hyp_kernel<1, true>), hgrid, hblock, 0, h->stream, p);
-                else hipLaunchKernelGGL((free_stage_hyp_kernel<1, false>), hgrid, hblock, 0, h->stream, p);
-            } else {
-                if (log) hipLaunchKernelGGL((free_stage_hyp_kernel<2, true>), hgrid, hblock, 0, h->stream, p);
-                else hipLaunchKernelGGL((free_stage_hyp_kernel<2, false>), hgrid, hblock, 0, h->stream, p);
-            }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(h->kev[li].second, h->stream));
             h->last_launches += 1;
@@ -1656,21 +1606,6 @@ extern "C" int sac_set_proposals_per_step(sac_handle_t *h, int32_t proposals_per
     if (proposals_per_step != 0 && proposals_per_step != 1 && proposals_per_step != 2 && proposals_per_step != 4)
         return fail(SAC_E_INVALID, "sac_set_proposals_per_step: %d (0 = automatic, 1, 2 or 4)", proposals_per_step);
     h->proposals_per_step = proposals_per_step;
-    return SAC_OK;
-}
-
-extern "C" int sac_set_hypothesis_pairs(sac_handle_t *h, int32_t mode)
-{
-    if (!h) return fail(SAC_E_INVALID, "sac_set_hypothesis_pairs: null handle");
-    if (mode < -1 || mode > 1) return fail(SAC_E_INVALID, "sac_set_hypothesis_pairs: %d (0 = automatic, 1 = on, -1 = off)", mode);
-    h->hyp_pairs = mode;
-    return SAC_OK;
-}
-
-extern "C" int sac_get_hypothesis_pairs(sac_handle_t *h, int32_t *last_used)
-{
-    if (!h || !last_used) return fail(SAC_E_INVALID, "sac_get_hypothesis_pairs: null argument");
-    *last_used = h->last_hyp_pairs;
     return SAC_OK;
 }
 

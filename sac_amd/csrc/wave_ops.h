@@ -64,30 +64,6 @@ __device__ __forceinline__ double wave_sum_lane63(double v)
     return v;
 }
 
-// Three independent sums, each in the canonical tree order of wave_sum_lane63, advanced level by level together: the
-// levels of one tree depend on each other (DPP read two wait states after the add that produced the value), the three
-// trees do not, so a wave that has nothing else to issue walks all three in little more than the time of one.  The
-// scheduling barriers keep the compiler from putting the trees back one behind the other.
-__device__ __forceinline__ void wave_sum_lane63_x3(double &a, double &b, double &c)
-{
-#define SAC_TREE_LEVEL(CTRL)                                                         \
-    do {                                                                             \
-        const double ta_ = dpp_f64<CTRL>(a), tb_ = dpp_f64<CTRL>(b), tc_ = dpp_f64<CTRL>(c); \
-        a = a + ta_;                                                                 \
-        b = b + tb_;                                                                 \
-        c = c + tc_;                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                           \
-    } while (0)
-    __builtin_amdgcn_sched_barrier(0);
-    SAC_TREE_LEVEL(0xB1);
-    SAC_TREE_LEVEL(0x4E);
-    SAC_TREE_LEVEL(0x141);
-    SAC_TREE_LEVEL(0x140);
-    SAC_TREE_LEVEL(0x142);
-    SAC_TREE_LEVEL(0x143);
-#undef SAC_TREE_LEVEL
-}
-
 __device__ __forceinline__ double wave_sum_uniform(double v)
 {
     return readlane_f64(wave_sum_lane63(v), 63);

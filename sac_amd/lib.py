@@ -23,7 +23,7 @@ EXPORTS = [
     "sac_edge_build_tables", "sac_edge_upload_data", "sac_edge_get_tables",
     "sac_get_gbar_mean", "sac_edge_get_gbar_mean", "sac_edge_get_move_means",
     "sac_edge_set_targets_from_chi2_min", "sac_edge_set_chain_targets", "sac_edge_get_first_passages", "sac_comm_unique_id", "sac_comm_init", "sac_comm_info", "sac_edge_comm_init", "sac_edge_comm_info",
-    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_set_proposals_per_step", "sac_get_proposals_per_step", "sac_set_hypothesis_pairs", "sac_get_hypothesis_pairs", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
+    "sac_set_chains_per_wave", "sac_get_chains_per_wave", "sac_set_proposals_per_step", "sac_get_proposals_per_step", "sac_replay_peak", "sac_edge_replay", "sac_validation_chi2", "sac_edge_validation_chi2",
 ]
 
 KIND_FREE, KIND_PEAK = 0, 1
@@ -162,8 +162,6 @@ def load_library():
     L.sac_get_chains_per_wave.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sac_set_proposals_per_step.argtypes = [vp, C.c_int32]
     L.sac_get_proposals_per_step.argtypes = [vp, C.POINTER(C.c_int32)]
-    L.sac_set_hypothesis_pairs.argtypes = [vp, C.c_int32]
-    L.sac_get_hypothesis_pairs.argtypes = [vp, C.POINTER(C.c_int32)]
     L.sac_get_gbar_mean.argtypes = [vp, dp]
     L.sac_edge_get_gbar_mean.argtypes = [vp, dp]
     L.sac_edge_get_move_means.argtypes = [vp, dp, dp, dp]
@@ -331,17 +329,6 @@ class SacHandle:
         """Proposals per step the last sweep launch ran with."""
         out = C.c_int32(0)
         self._check(self.L.sac_get_proposals_per_step(self.h, C.byref(out)))
-        return out.value
-
-    def set_hypothesis_pairs(self, mode):
-        """0 = the library chooses, 1 = on, -1 = off: proposals of a chain resolved two at a time as a hypothesis pair (runs
-        with few chains: same chain, shorter latency)."""
-        self._check(self.L.sac_set_hypothesis_pairs(self.h, int(mode)))
-
-    def hypothesis_pairs(self):
-        """Whether the last sweep launch resolved its proposals as hypothesis pairs."""
-        out = C.c_int32(0)
-        self._check(self.L.sac_get_hypothesis_pairs(self.h, C.byref(out)))
         return out.value
 
     def comm_init(self, unique_id, rank, world):
