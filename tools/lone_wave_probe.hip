@@ -91,6 +91,47 @@ __global__ void probe(double *out, unsigned long long *cyc, unsigned long long *
         END();
         a += e;
     }
+    // 9: independent v_mul_hi_u32 (4 chains): integer multiplies run at a quarter of the rate
+    {
+        uint32_t x0 = lane + 1, x1 = lane + 2, x2 = lane + 3, x3 = lane + 4;
+        const uint32_t m = (uint32_t)seed + 0xD2511F52u;
+        BEGIN();
+#pragma unroll
+        for (int i = 0; i < REP; ++i) {
+            asm volatile("v_mul_hi_u32 %0, %0, %4\n v_mul_hi_u32 %1, %1, %4\n v_mul_hi_u32 %2, %2, %4\n v_mul_hi_u32 %3, %3, %4"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "s"(m));
+        }
+        END();
+        a += x0 + x1 + x2 + x3;
+    }
+    // 10: independent v_mad_u64_u32 (4 chains): the full 64-bit product in one instruction
+    {
+        uint32_t x0 = lane + 1, x1 = lane + 2, x2 = lane + 3, x3 = lane + 4;
+        unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        const uint32_t m = (uint32_t)seed + 0xD2511F52u;
+        BEGIN();
+#pragma unroll
+        for (int i = 0; i < REP; ++i) {
+            asm volatile("v_mad_u64_u32 %0, vcc, %4, %8, 0\n v_mad_u64_u32 %1, vcc, %5, %8, 0\n v_mad_u64_u32 %2, vcc, %6, %8, 0\n v_mad_u64_u32 %3, vcc, %7, %8, 0"
+                         : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(m) : "vcc");
+            x0 = (uint32_t)(p0 >> 32); x1 = (uint32_t)(p1 >> 32); x2 = (uint32_t)(p2 >> 32); x3 = (uint32_t)(p3 >> 32);
+        }
+        END();
+        a += (double)(p0 + p1 + p2 + p3);
+    }
+    // 11: independent v_mul_lo_u32 (4 chains)
+    {
+        uint32_t x0 = lane + 1, x1 = lane + 2, x2 = lane + 3, x3 = lane + 4;
+        const uint32_t m = (uint32_t)seed + 0xD2511F52u;
+        BEGIN();
+#pragma unroll
+        for (int i = 0; i < REP; ++i) {
+            asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "s"(m));
+        }
+        END();
+        a += x0 + x1 + x2 + x3;
+    }
     out[blockIdx.x * 64 + lane] = a + b + c;
 }
 
@@ -101,8 +142,9 @@ int main()
     const char *names[] = {"dependent v_add_f64 (per add)", "3 independent v_add_f64 chains (per add)", "dependent tree level: 2 DPP mov + add (per level)",
                            "3 interleaved tree levels (per level)", "readlane x2 -> v_add_f64 with scalar operand (per round trip)",
                            "independent v_add_u32 (per instr)", "independent s_add_u32 (per instr)", "v_cmp + ballot test + scalar branch + add (per round)",
-                           "4 independent v_mul_f64 chains (per mul)"};
-    const int per[] = {REP, 3 * REP, REP, 3 * REP, REP, 4 * REP, 4 * REP, REP, 4 * REP};
+                           "4 independent v_mul_f64 chains (per mul)", "4 independent v_mul_hi_u32 chains (per instr)",
+                           "4 independent v_mad_u64_u32 chains (per instr)", "4 independent v_mul_lo_u32 chains (per instr)"};
+    const int per[] = {REP, 3 * REP, REP, 3 * REP, REP, 4 * REP, 4 * REP, REP, 4 * REP, 4 * REP, 4 * REP, 4 * REP};
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, out, cyc, real, 1.0);
         hipDeviceSynchronize();
@@ -110,7 +152,7 @@ int main()
     unsigned long long h[16], r[16];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     hipMemcpy(r, real, sizeof(r), hipMemcpyDeviceToHost);
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < 12; ++k)
         printf("%-62s s_memtime %8.2f   s_memrealtime ticks %8.3f\n", names[k], (double)h[k] / per[k], (double)r[k] / per[k]);
     // the clock: a long dependent chain timed by the host
     return 0;
