@@ -136,9 +136,11 @@ class PeakSAC:
 
     def __init__(self, N_omega, N_p, A_0, omega_m, d_omega, d_omega_h, theta_0, f_anneal, a_criterion,
                  N_anneal, anneal_steps, sample_steps, G_file, output_folder, fix_edge, symm, kernel_type,
-                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None, chi2_min_mode="chain_mean"):
+                 n_chains=1, seed=0, tol=1e-3, device=0, timedata=None, comm=None, chi2_min_mode="chain_mean",
+                 device_tables=False):
         if chi2_min_mode not in ("chain_mean", "min"):
             raise ValueError("chi2_min_mode must be 'chain_mean' or 'min'")
+        self.device_tables = bool(device_tables)   # Kp / Kn built on the GPU (sac_build_table, row f1) instead of peak:248-276 on the host
         self.chi2_min_mode = chi2_min_mode      # see FreeSAC: the single-chain equivalent of the reference's chi2_min, or the minimum
         self.comm = comm
         self.is_root = comm is None or comm.rank == 0
@@ -231,7 +233,8 @@ class PeakSAC:
                                 omega_0=self.omega_0, fix_edge=self.fix_edge, symm=self.symm,
                                 kernel_type=self.kernel_type)
         offset = 0 if self.comm is None else self.comm.rank * self.n_chains
-        self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device, chain_offset=offset)
+        self.h = self.prob.make_handle(n_chains=self.n_chains, seed=self.seed, device=self.device, chain_offset=offset,
+                                       device_tables=self.device_tables)
         self.h.set_indiv_update(self.indiv_update)
         if self.comm is not None:
             self.comm.attach(self.h)                                # RCCL groups: the merge goes behind the C ABI

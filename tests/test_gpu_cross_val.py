@@ -20,7 +20,7 @@ def test_free_cv_gsac_follows_reference(tmp_path):
     rows[4] = f"{CV} {tmp_path}/out"
     in_file = tmp_path / "in_free.in"
     in_file.write_text("\n".join(rows))
-    s = free_cv(1, "a", in_file=str(in_file), n_chains=64, seed=77)
+    s = free_cv(1, "a", in_file=str(in_file), n_chains=64, seed=77, device_tables=True)
     assert s.output_folder.endswith("/001a/free") and s.tol == 1e-6
     got = np.loadtxt(s.output_folder + "/GSAC.csv", delimiter=",")
     ref = np.loadtxt(f"{CV}/GSAC_free_001a.csv", delimiter=",")

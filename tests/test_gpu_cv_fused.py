@@ -47,7 +47,7 @@ def test_fused_scores_equal_the_file_route(tmp_path):
     in_file.write_text("\n".join(rows))
     runs = {}
     for ab, other in (("a", "b"), ("b", "a")):
-        runs[ab] = cross_val.free_cv(1, ab, in_file=str(in_file), n_chains=8, seed=3,
+        runs[ab] = cross_val.free_cv(1, ab, in_file=str(in_file), n_chains=8, seed=3, device_tables=True,
                                      validate_tin=f"{CV}/t_001{other}.in")
     for ab, other in (("a", "b"), ("b", "a")):
         s = runs[ab]

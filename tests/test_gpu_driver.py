@@ -22,7 +22,7 @@ def test_anneal_curve_follows_reference_run(tmp_path):
         z = (m - ref) / (s * sqrt(1 + 1/64))
     is standard normal.  Required: |z| < 4 at every Theta, <z^2> < 2, |<z>| < 0.6 (measured: max 2.6, 1.2, 0.35)."""
     n_chains, n_pts = 64, 60
-    s = FreeSAC.from_infile(f"{CV}/run001a_free_in_free.in", n_chains=n_chains, seed=2025)
+    s = FreeSAC.from_infile(f"{CV}/run001a_free_in_free.in", n_chains=n_chains, seed=2025, device_tables=True)
     s.G_file = f"{CV}/t_001a.in"
     s.output_folder = str(tmp_path / "out")
     assert (s.anneal_steps, s.N_anneal) == (500, 150)
@@ -80,7 +80,7 @@ def test_complete_run_reproduces_reference_spectrum(tmp_path):
     (its in_free.in with the full schedule: 150 x 500 sweeps, 5000 sampling sweeps; t.in; anneal.csv; sample.csv; the
     final spectrum sw000.csv).  The same run here, many chains: the Theta ladder must stop at the same point, and the
     spectrum -- delta peak at omega = 1 plus continuum -- must coincide in position, height, mean and distribution."""
-    s = FreeSAC.from_infile(f"{BDP}/in_free.in", n_chains=128, seed=7)
+    s = FreeSAC.from_infile(f"{BDP}/in_free.in", n_chains=128, seed=7, device_tables=True)
     s.G_file = f"{BDP}/t.in"
     s.output_folder = str(tmp_path / "out")
     # the reference's ladder and stop rules with half its sweeps per stage (250 / 2500 instead of 500 / 5000) on 128

@@ -82,7 +82,7 @@ def test_edge_anneal_follows_reference_run(tmp_path):
 
 
 def test_edge_reference_schedule_z_test(tmp_path):
-    """The first 8 points of the reference's own Theta ladder with the reference's own sweeps per stage (equilibration
+    """The first 6 points of the reference's own Theta ladder with the reference's own sweeps per stage (equilibration
     5 x 600 x 20, then 20 bins of 600 (1 - i / 48) sweeps per Theta; only the kernel grid is 10 x coarser) on 32 chains.  The
     reference's anneal.csv holds ONE chain's stage averages; a GPU chain's stage average is a draw from the same distribution
     if the samplers agree, so with m, s the mean and scatter over the 32 GPU chains
@@ -92,7 +92,7 @@ def test_edge_reference_schedule_z_test(tmp_path):
     the chains' own scatter is the yardstick: tools/edge_full_check.py, profiles/r02_edge_full_anneal_check.txt, does the same
     over the reference's complete first anneal: 120 stages, max |z| 2.3, rms 0.67.)  Required: |z| < 4 at every Theta and a
     mean z within +-1.5 for each of the three observables."""
-    n_chains, n_pts = 32, 8
+    n_chains, n_pts = 32, 6
     s = EdgeSAC.from_infile(f"{REF}/in_edge.in", n_chains=n_chains, seed=3)
     s.G_file = f"{REF}/t.in"
     s.output_folder = str(tmp_path / "out")

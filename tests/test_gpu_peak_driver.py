@@ -14,7 +14,7 @@ REF = os.path.join(os.path.dirname(__file__), "golden", "peak_f2")
 
 
 def test_peak_anneal_follows_reference_run(tmp_path):
-    s = PeakSAC.from_infile(f"{REF}/in_peak.in", n_chains=32, seed=11)
+    s = PeakSAC.from_infile(f"{REF}/in_peak.in", n_chains=32, seed=11, device_tables=True)     # two 1.5-million-column tables
     assert (s.N_omega, s.N_p, s.A_0, s.d_omega, s.kernel_type, s.theta_0) == (2000, 1, 0.7, 1e-5, "finiteT", 15.0)
     s.G_file = f"{REF}/t.in"
     s.output_folder = str(tmp_path / "out")
@@ -100,7 +100,7 @@ def test_peak_anneal_reference_schedule_z_test(tmp_path):
     is standard normal if both sample the same distribution.  Required: |z| < 4 everywhere, <z^2> < 2, |<z>| < 0.6
     (measured: 2.2, 1.15, 0.25)."""
     n_chains, n_pts = 64, 50
-    s = PeakSAC.from_infile(f"{CVP}/in_peak.in", n_chains=n_chains, seed=11)
+    s = PeakSAC.from_infile(f"{CVP}/in_peak.in", n_chains=n_chains, seed=11, device_tables=True)
     assert (s.N_omega, s.N_p, s.kernel_type, s.fix_edge, s.anneal_steps, s.f_anneal) == (1000, 1, "bosonic", 1, 500, 1.1)
     s.G_file = CVT
     s.output_folder = str(tmp_path / "out")

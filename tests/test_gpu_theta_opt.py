@@ -5,7 +5,9 @@ added, and so would Theta_opt.  The drivers' default (chi2_min_mode="chain_mean"
 the chains of each chain's own chi2_min, and for the edge rule the median of the chains' own first passages.  Each test runs the
 reference's ladder and stop rules on few and on many chains (different seeds, fewer sweeps per stage than the reference to keep
 the suite short) and requires the same ladder point or a close neighbour, and the reference run's own Theta_opt nearby."""
+import multiprocessing as mp
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import pytest
@@ -18,8 +20,23 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def _together(*jobs, processes=False):
+    """Runs side by side: they are independent handles, every one leaves most of the GPU idle (at most 64 wavefronts) and its
+    wall-clock is the latency of its chains, so together they take about the time of the longest.  Host threads for the free and
+    peak drivers (handles are per driver task; the library's error state is thread-local); separate processes for the edge
+    driver, whose stage calls copy their scalar blocks on the null stream, which waits for every other handle of a process."""
+    if processes:
+        with mp.get_context("spawn").Pool(len(jobs)) as pool:
+            results = [pool.apply_async(job[0], job[1:]) for job in jobs]
+            return [r.get(timeout=560) for r in results]
+    with ThreadPoolExecutor(len(jobs)) as ex:
+        futures = [ex.submit(*job) for job in jobs]
+        return [f.result() for f in futures]
+
+
 def _free_theta(tmp_path, n_chains, seed, mode):
-    s = FreeSAC.from_infile(f"{G}/free_bdp/in_free.in", n_chains=n_chains, seed=seed, chi2_min_mode=mode)
+    s = FreeSAC.from_infile(f"{G}/free_bdp/in_free.in", n_chains=n_chains, seed=seed, chi2_min_mode=mode,
+                            device_tables=True)          # 1.5 million columns: 14 s on the host, 1 ms on the device (row f1)
     s.G_file = f"{G}/free_bdp/t.in"
     s.output_folder = str(tmp_path / f"free_{n_chains}_{mode}")
     s.anneal_steps //= 2                                   # 250 + 250 sweeps per Theta (reference: 500 + 500)
@@ -34,9 +51,8 @@ def _free_theta(tmp_path, n_chains, seed, mode):
 def test_free_theta_opt_is_independent_of_the_chain_count(tmp_path):
     ref_theta = np.loadtxt(f"{G}/free_bdp/sample.csv", delimiter=",", skiprows=1, ndmin=2)[0][2]
     step = np.log(1.1)                                     # f_anneal of the run
-    few, c_few, _ = _free_theta(tmp_path, 4, 21, "chain_mean")
-    many, c_many, c_all = _free_theta(tmp_path, 64, 7, "chain_mean")
-    low, _, _ = _free_theta(tmp_path, 64, 7, "min")
+    (few, c_few, _), (many, c_many, c_all), (low, _, _) = _together(
+        (_free_theta, tmp_path, 4, 21, "chain_mean"), (_free_theta, tmp_path, 64, 7, "chain_mean"), (_free_theta, tmp_path, 64, 7, "min"))
     print("free theta_opt: 4 chains", few, "64 chains", many, "64 chains, minimum over chains", low, "reference", ref_theta,
           "chi2_min/N", c_few, c_many, c_all)
     assert abs(np.log(few / many)) <= 2.01 * step
@@ -46,7 +62,7 @@ def test_free_theta_opt_is_independent_of_the_chain_count(tmp_path):
 
 
 def _peak_theta(tmp_path, n_chains, seed):
-    s = PeakSAC.from_infile(f"{G}/peak_cv001a/in_peak.in", n_chains=n_chains, seed=seed)
+    s = PeakSAC.from_infile(f"{G}/peak_cv001a/in_peak.in", n_chains=n_chains, seed=seed, device_tables=True)
     s.G_file = f"{G}/cv/t_001a.in"
     s.output_folder = str(tmp_path / f"peak_{n_chains}")
     s.anneal_steps //= 2
@@ -61,8 +77,7 @@ def _peak_theta(tmp_path, n_chains, seed):
 
 def test_peak_theta_opt_is_independent_of_the_chain_count(tmp_path):
     step = np.log(1.1)
-    few, c_few, _, _ = _peak_theta(tmp_path, 4, 5)
-    many, c_many, a_crit, n_tau = _peak_theta(tmp_path, 64, 11)
+    (few, c_few, _, _), (many, c_many, a_crit, n_tau) = _together((_peak_theta, tmp_path, 4, 5), (_peak_theta, tmp_path, 64, 11))
     # the reference run (cross-validation leg: no sample.csv) fixes Theta_opt through its anneal.csv: peak:1545-1548 applied to
     # the columns it printed (chi2_min / N_tau of the last row, <chi2> / N_tau per Theta, both rounded to 4 digits)
     ref = np.loadtxt(f"{G}/peak_cv001a/anneal.csv", delimiter=",", skiprows=1)
@@ -85,7 +100,8 @@ def _edge_theta(tmp_path, n_chains, seed):
     s.N_anneal, s.anneal_steps, s.sample_steps = 30, 300, 100
     s.chi2_anneal = np.zeros(s.N_anneal)
     theta = s.run()
-    fp = s.first_passages
+    fp = np.array(s.first_passages)
+    s.h.close()
     return theta, fp, s.f_anneal
 
 
@@ -93,8 +109,8 @@ def test_edge_theta_opt_is_the_median_first_passage_at_any_chain_count(tmp_path)
     """edge:1680 stops at ONE chain's first passage, a broad distribution (profiles/r03_time_to_solution_edge.jsonl: the 10 % - 90 %
     range of the 64 chains of the full run spans a factor > 3 in Theta; the reference's own run sits at its 12th percentile).  The
     many-chain rule stops when half the chains have passed: its Theta_opt is the median of that distribution, whatever the count."""
-    few, fp_few, f = _edge_theta(tmp_path, 16, 9)
-    many, fp_many, _ = _edge_theta(tmp_path, 64, 3)
+    (few, fp_few, f), (many, fp_many, _), (one, fp_one, _) = _together(
+        (_edge_theta, tmp_path, 16, 9), (_edge_theta, tmp_path, 64, 3), (_edge_theta, tmp_path, 1, 5), processes=True)
     print("edge theta_opt: 16 chains", few, "64 chains", many, "passages", np.sort(fp_few[fp_few > 0]), np.sort(fp_many[fp_many > 0]))
     # The first-passage distribution is broad and flat around its middle (stages 6 ... 21 on this ladder), so the comparison is made
     # in quantiles, not in ladder stages: by the stage at which the 16-chain run stopped, between a quarter and three quarters of
@@ -109,5 +125,4 @@ def test_edge_theta_opt_is_the_median_first_passage_at_any_chain_count(tmp_path)
         crossed = (fp > 0).sum()
         assert 2 * crossed >= len(fp) and 2 * (crossed - (fp == fp.max()).sum()) < len(fp)     # stopped at the stage the median chain passed
     # a single chain follows the reference's rule to the letter: the stage of ITS first passage
-    one, fp_one, _ = _edge_theta(tmp_path, 1, 5)
     assert (fp_one > 0).all() and one == pytest.approx(10.0 / f ** (int(fp_one[0]) - 2), rel=1e-12)
