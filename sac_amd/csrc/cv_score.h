@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 #include "wave_ops.h"
+#include "devbuf.h"
 
 namespace sacdev {
 
@@ -79,7 +80,7 @@ static inline hipError_t cv_score_run(hipStream_t stream, const double *d_gbar, 
     std::memcpy(host.data() + 2 * mat, G_other, nt * sizeof(double));
     std::memcpy(host.data() + 2 * mat + 128, sinv_other, nt * sizeof(double));
     if (gbar_mean) std::memcpy(host.data() + 2 * mat + 256, gbar_mean, nt * sizeof(double));
-    e = hipMemcpy(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
+    e = copy_sync(stream, d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         sacdev::CvScoreArgs a;
         a.gbar = d_gbar; a.mean_in = gbar_mean ? d + 2 * mat + 256 : nullptr;
@@ -91,7 +92,7 @@ static inline hipError_t cv_score_run(hipStream_t stream, const double *d_gbar, 
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e == hipSuccess) {
             std::vector<double> out(1 + (size_t)n_chains);
-            e = hipMemcpy(out.data(), a.out, out.size() * sizeof(double), hipMemcpyDeviceToHost);
+            e = copy_sync(stream, out.data(), a.out, out.size() * sizeof(double), hipMemcpyDeviceToHost);
             if (e == hipSuccess) {
                 if (chi2_mean) *chi2_mean = out[0];
                 if (chi2_chain) std::memcpy(chi2_chain, out.data() + 1, (size_t)n_chains * sizeof(double));

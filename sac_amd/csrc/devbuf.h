@@ -4,6 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+// A copy that is ordered on the given stream and complete on return.  The plain hipMemcpy runs on the null stream, which waits for
+// -- and holds up -- the streams of every other handle of the process: independent runs that share a GPU as host threads (scan
+// points, cross-validation units) would take turns instead of running side by side.
+static inline hipError_t copy_sync(hipStream_t st, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 struct DevBuf {
     void *p = nullptr;
     DevBuf() = default;

@@ -720,16 +720,16 @@ extern "C" int sac_edge_upload_problem(sac_edge_t *h, const double *const *K, co
             for (size_t i = 0; i < n; ++i)
                 for (int q = 0; q < 3; ++q)
                     std::memcpy(&stage[(i * 3 + q) * ntp], src[q] + (a + i) * nt, nt * sizeof(double));
-            HIP_TRY(hipMemcpy(h->dTab[rl] + a * 3 * ntp, stage.data(), n * 3 * ntp * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(h->stream, h->dTab[rl] + a * 3 * ntp, stage.data(), n * 3 * ntp * sizeof(double), hipMemcpyHostToDevice));
         }
     }
     double pad[SAC_MAX_N_TAU];
     std::memset(pad, 0, sizeof(pad));
     std::memcpy(pad, G, nt * sizeof(double));
-    HIP_TRY(hipMemcpy(h->dG, pad, sizeof(pad), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dG, pad, sizeof(pad), hipMemcpyHostToDevice));
     std::memset(pad, 0, sizeof(pad));
     std::memcpy(pad, sigma_inv, nt * sizeof(double));
-    HIP_TRY(hipMemcpy(h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
     h->problem = true;
     return SAC_OK;
 }
@@ -740,10 +740,10 @@ static int upload_data(sac_edge *h, const double *G, const double *sigma_inv)
     double pad[SAC_MAX_N_TAU];
     std::memset(pad, 0, sizeof(pad));
     std::memcpy(pad, G, nt * sizeof(double));
-    HIP_TRY(hipMemcpy(h->dG, pad, sizeof(pad), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dG, pad, sizeof(pad), hipMemcpyHostToDevice));
     std::memset(pad, 0, sizeof(pad));
     std::memcpy(pad, sigma_inv, nt * sizeof(double));
-    HIP_TRY(hipMemcpy(h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dSinv, pad, sizeof(pad), hipMemcpyHostToDevice));
     return SAC_OK;
 }
 
@@ -773,8 +773,8 @@ extern "C" int sac_edge_build_tables(sac_edge_t *h, int32_t side, const sac_tabl
     double *d_tau = nullptr, *d_U = nullptr;
     HIP_TRY(hipMalloc(&d_tau, nt * sizeof(double)));
     if (hipMalloc(&d_U, nt * nt * sizeof(double)) != hipSuccess) { (void)hipFree(d_tau); return efail(SAC_E_HIP, "sac_edge_build_tables: out of device memory"); }
-    hipError_t e = hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e = copy_sync(h->stream, d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = copy_sync(h->stream, d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         TableSpec sp;
         sp.kernel_type = spec->kernel_type; sp.n_tau = (int)nt; sp.mirror = spec->mirror; sp.negate = spec->negate;
@@ -844,7 +844,7 @@ extern "C" int sac_edge_set_state(sac_edge_t *h, int32_t chain, const double *w,
             for (int k = 1; k <= n1; ++k) one[(size_t)rl * S + k] = src[rl * n1 + k - 1];
         std::vector<double> all((size_t)count * one.size());
         for (int c = 0; c < count; ++c) std::memcpy(all.data() + (size_t)c * one.size(), one.data(), one.size() * sizeof(double));
-        HIP_TRY(hipMemcpy(dst + (size_t)first * one.size(), all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, dst + (size_t)first * one.size(), all.data(), all.size() * sizeof(double), hipMemcpyHostToDevice));
         return SAC_OK;
     };
     if (w && (rc = put_d(h->dW, w))) return rc;
@@ -856,16 +856,16 @@ extern "C" int sac_edge_set_state(sac_edge_t *h, int32_t chain, const double *w,
             for (int k = 1; k <= n1; ++k) one[(size_t)rl * S + k] = (int)n_multi[rl * n1 + k - 1];
         std::vector<int> all((size_t)count * one.size());
         for (int c = 0; c < count; ++c) std::memcpy(all.data() + (size_t)c * one.size(), one.data(), one.size() * sizeof(int));
-        HIP_TRY(hipMemcpy(h->dNm + (size_t)first * one.size(), all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dNm + (size_t)first * one.size(), all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     if (scal8) {
         std::vector<EdgeScalars> sc((size_t)count);
-        HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
         for (auto &s : sc)
             for (int rl = 0; rl < 2; ++rl) {
                 s.n0[rl] = scal8[rl]; s.eps0[rl] = scal8[2 + rl]; s.dn0[rl] = scal8[4 + rl]; s.deps0[rl] = scal8[6 + rl];
             }
-        HIP_TRY(hipMemcpy(h->dSc + first, sc.data(), sc.size() * sizeof(EdgeScalars), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dSc + first, sc.data(), sc.size() * sizeof(EdgeScalars), hipMemcpyHostToDevice));
     }
     if (w && A) h->state_set = true;
     if (w || A) h->gbar_set = false;
@@ -883,7 +883,7 @@ extern "C" int sac_edge_get_state(sac_edge_t *h, int32_t chain, double *w, doubl
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::vector<double> one(2 * (size_t)S);
     auto get_d = [&](const double *src, double *dst) -> int {
-        HIP_TRY(hipMemcpy(one.data(), src + (size_t)chain * one.size(), one.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, one.data(), src + (size_t)chain * one.size(), one.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int rl = 0; rl < 2; ++rl)
             for (int k = 1; k <= n1; ++k) dst[rl * n1 + k - 1] = one[(size_t)rl * S + k];
         return SAC_OK;
@@ -893,13 +893,13 @@ extern "C" int sac_edge_get_state(sac_edge_t *h, int32_t chain, double *w, doubl
     if (dw && (rc = get_d(h->dDw, dw))) return rc;
     if (n_multi) {
         std::vector<int> oi(2 * (size_t)S);
-        HIP_TRY(hipMemcpy(oi.data(), h->dNm + (size_t)chain * oi.size(), oi.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, oi.data(), h->dNm + (size_t)chain * oi.size(), oi.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int rl = 0; rl < 2; ++rl)
             for (int k = 1; k <= n1; ++k) n_multi[rl * n1 + k - 1] = oi[(size_t)rl * S + k];
     }
     if (scal8) {
         EdgeScalars s;
-        HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
         for (int rl = 0; rl < 2; ++rl) {
             scal8[rl] = s.n0[rl]; scal8[2 + rl] = s.eps0[rl]; scal8[4 + rl] = s.dn0[rl]; scal8[6 + rl] = s.deps0[rl];
         }
@@ -1001,14 +1001,14 @@ extern "C" int sac_edge_run_bins(sac_edge_t *h, int64_t steps, int64_t bins, dou
     {
         HIP_TRY(hipStreamSynchronize(h->stream));
         std::vector<EdgeScalars> sc(nc);
-        HIP_TRY(hipMemcpy(sc.data(), h->dSc, nc * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, sc.data(), h->dSc, nc * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
         for (auto &s : sc) {
             std::memset(s.chi2_res, 0, sizeof(s.chi2_res));
             std::memset(s.edge_res, 0, sizeof(s.edge_res));
             std::memset(s.n0_res, 0, sizeof(s.n0_res));
             std::memset(s.wn0_res, 0, sizeof(s.wn0_res));
         }
-        HIP_TRY(hipMemcpy(h->dSc, sc.data(), nc * sizeof(EdgeScalars), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dSc, sc.data(), nc * sizeof(EdgeScalars), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemsetAsync(h->dHist, 0, (size_t)h->hist_copies * 4 * (size_t)h->cfg.n_grid * sizeof(double), h->stream));
     HIP_TRY(hipMemsetAsync(h->dWavg, 0, nc * 2 * S * sizeof(double), h->stream));
@@ -1103,14 +1103,14 @@ extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_resul
         out->n_chains_total = (int64_t)n;
         out->chains_below_target = (int64_t)t[45];
         EdgeScalars last;
-        HIP_TRY(hipMemcpy(&last, h->dSc + (nc - 1), sizeof(last), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &last, h->dSc + (nc - 1), sizeof(last), hipMemcpyDeviceToHost));
         out->sweeps = last.sweep;
         out->last_stage_ms = h->last_stage_ms;
         return SAC_OK;
     }
     const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
     std::vector<EdgeScalars> sc((size_t)count);
-    HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, sc.data(), h->dSc + first, sc.size() * sizeof(EdgeScalars), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     out->chi2_min = 1e300;
     for (const auto &s : sc) {
@@ -1140,7 +1140,7 @@ extern "C" int sac_edge_get_results(sac_edge_t *h, int32_t chain, sac_edge_resul
     out->n_chains_total = count;
     if (h->targets_on) {
         std::vector<int> pass((size_t)count);
-        HIP_TRY(hipMemcpy(pass.data(), h->dPass + first, pass.size() * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, pass.data(), h->dPass + first, pass.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int v : pass) out->chains_below_target += (v != 0) ? 1 : 0;
     }
     out->last_stage_ms = h->last_stage_ms;
@@ -1158,7 +1158,7 @@ extern "C" int sac_edge_get_accept_rates(sac_edge_t *h, int32_t chain, int32_t m
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (chain < 0 && h->comm && h->comm->merged) {                   // mean over all ranks' chains (edge_comm_merge)
-        HIP_TRY(hipMemcpy(out, h->comm->dSum + h->off_arc() + ((size_t)side * 2 + (size_t)m) * (size_t)n1, (size_t)n1 * sizeof(double),
+        HIP_TRY(copy_sync(h->stream, out, h->comm->dSum + h->off_arc() + ((size_t)side * 2 + (size_t)m) * (size_t)n1, (size_t)n1 * sizeof(double),
                           hipMemcpyDeviceToHost));
         const double n = h->comm->hTail[42];
         for (int k = 0; k < n1; ++k) out[k] = out[k] / n;
@@ -1166,7 +1166,7 @@ extern "C" int sac_edge_get_accept_rates(sac_edge_t *h, int32_t chain, int32_t m
     }
     const int first = chain < 0 ? 0 : chain, count = chain < 0 ? nc : 1;
     std::vector<double> buf((size_t)count * 4 * S);
-    HIP_TRY(hipMemcpy(buf.data(), h->dArc + (size_t)first * 4 * S, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, buf.data(), h->dArc + (size_t)first * 4 * S, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int k = 1; k <= n1; ++k) out[k - 1] = 0.0;
     for (int c = 0; c < count; ++c)
         for (int k = 1; k <= n1; ++k) out[k - 1] += buf[(size_t)c * 4 * S + ((size_t)side * 2 + m) * S + k] / count;
@@ -1183,7 +1183,7 @@ extern "C" int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ng = (size_t)h->cfg.n_grid;
     if (h->comm && h->comm->merged) {                                // mean over all ranks' chains (edge_comm_merge)
-        HIP_TRY(hipMemcpy(out, h->comm->dSum + ((size_t)side * 2 + (size_t)which) * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, out, h->comm->dSum + ((size_t)side * 2 + (size_t)which) * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
         const double n = h->comm->hTail[42];
         if (n > 1)
             for (size_t i = 0; i < ng; ++i) out[i] = out[i] / n;
@@ -1192,7 +1192,7 @@ extern "C" int sac_edge_get_histogram(sac_edge_t *h, int32_t which, int32_t side
     std::vector<double> tmp(ng);
     for (size_t i = 0; i < ng; ++i) out[i] = 0.0;
     for (int c = 0; c < h->hist_copies; ++c) {
-        HIP_TRY(hipMemcpy(tmp.data(), h->dHist + ((size_t)c * 4 + (size_t)side * 2 + which) * ng, ng * sizeof(double),
+        HIP_TRY(copy_sync(h->stream, tmp.data(), h->dHist + ((size_t)c * 4 + (size_t)side * 2 + which) * ng, ng * sizeof(double),
                           hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ng; ++i) out[i] = out[i] + tmp[i];
     }
@@ -1216,7 +1216,7 @@ extern "C" int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, dou
         for (int pass = 0; pass < 2; ++pass) {
             double *dst = pass == 0 ? w_avg : A_avg;
             if (!dst) continue;
-            HIP_TRY(hipMemcpy(dst, h->comm->dSum + (pass == 0 ? h->off_wavg() : h->off_aavg()), (size_t)(2 * n1) * sizeof(double),
+            HIP_TRY(copy_sync(h->stream, dst, h->comm->dSum + (pass == 0 ? h->off_wavg() : h->off_aavg()), (size_t)(2 * n1) * sizeof(double),
                               hipMemcpyDeviceToHost));
             for (int i = 0; i < 2 * n1; ++i) dst[i] = dst[i] / n;
         }
@@ -1227,7 +1227,7 @@ extern "C" int sac_edge_get_avg(sac_edge_t *h, int32_t chain, double *w_avg, dou
     for (int pass = 0; pass < 2; ++pass) {
         double *dst = pass == 0 ? w_avg : A_avg;
         if (!dst) continue;
-        HIP_TRY(hipMemcpy(buf.data(), (pass == 0 ? h->dWavg : h->dAavg) + (size_t)first * 2 * S, buf.size() * sizeof(double),
+        HIP_TRY(copy_sync(h->stream, buf.data(), (pass == 0 ? h->dWavg : h->dAavg) + (size_t)first * 2 * S, buf.size() * sizeof(double),
                           hipMemcpyDeviceToHost));
         for (int i = 0; i < 2 * n1; ++i) dst[i] = 0.0;
         for (int c = 0; c < count; ++c)
@@ -1369,8 +1369,8 @@ extern "C" int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const
     dC = b_dC.as<std::remove_pointer_t<decltype(dC)>>();
     HIP_TRY(b_dAcc.alloc((size_t)n * sizeof(int)));
     dAcc = b_dAcc.as<std::remove_pointer_t<decltype(dAcc)>>();
-    HIP_TRY(hipMemcpy(dP, props, (size_t)n * sizeof(EdgeReplayProp), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dW, w_new, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, dP, props, (size_t)n * sizeof(EdgeReplayProp), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, dW, w_new, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice));
     EdgeParams p;
     fill_params(h, p);
     p.inv2theta = 1.0 / (2.0 * theta);
@@ -1378,8 +1378,8 @@ extern "C" int sac_edge_replay(sac_edge_t *h, int32_t chain, double theta, const
     else hipLaunchKernelGGL(edge_replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dW, dC, dAcc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (chi2_new) HIP_TRY(copy_sync(h->stream, chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(copy_sync(h->stream, accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return SAC_OK;
 }
 
@@ -1409,9 +1409,9 @@ extern "C" int sac_edge_get_gbar(sac_edge_t *h, int32_t chain, double *gbar, dou
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (gbar)
-        HIP_TRY(hipMemcpy(gbar, h->dGbar + (size_t)chain * SAC_MAX_N_TAU, (size_t)h->cfg.n_tau * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, gbar, h->dGbar + (size_t)chain * SAC_MAX_N_TAU, (size_t)h->cfg.n_tau * sizeof(double), hipMemcpyDeviceToHost));
     EdgeScalars s;
-    HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, &s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
     if (chi2) *chi2 = s.chi2;
     if (chi2_min) *chi2_min = s.chi2_min;
     return SAC_OK;
@@ -1467,7 +1467,7 @@ extern "C" int sac_edge_set_chain_targets(sac_edge_t *h, const double *targets)
     HIP_TRY(hipMemset(h->dPass, 0, nc * sizeof(int)));
     h->targets_on = (targets != nullptr);
     h->stages_since_targets = 0;
-    if (targets) HIP_TRY(hipMemcpy(h->dTargets, targets, nc * sizeof(double), hipMemcpyHostToDevice));
+    if (targets) HIP_TRY(copy_sync(h->stream, h->dTargets, targets, nc * sizeof(double), hipMemcpyHostToDevice));
     if (h->comm) h->comm->merged = false;
     return SAC_OK;
 }
@@ -1479,7 +1479,7 @@ extern "C" int sac_edge_get_first_passages(sac_edge_t *h, int32_t *stage)
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
-    HIP_TRY(hipMemcpy(stage, h->dPass, (size_t)h->cfg.n_chains * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, stage, h->dPass, (size_t)h->cfg.n_chains * sizeof(int), hipMemcpyDeviceToHost));
     return SAC_OK;
 }
 
@@ -1493,7 +1493,7 @@ extern "C" int sac_edge_get_move_means(sac_edge_t *h, double *dw_mean, double *n
     std::vector<double> buf(4 * (size_t)n1 + 2, 0.0);
     double n = (double)nc;
     if (h->comm && h->comm->merged) {                                // summed over all ranks' chains (edge_comm_merge)
-        HIP_TRY(hipMemcpy(buf.data(), h->comm->dSum + h->off_dw(), 4 * (size_t)n1 * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, buf.data(), h->comm->dSum + h->off_dw(), 4 * (size_t)n1 * sizeof(double), hipMemcpyDeviceToHost));
         buf[4 * (size_t)n1] = h->comm->hTail[43];
         buf[4 * (size_t)n1 + 1] = h->comm->hTail[44];
         n = h->comm->hTail[42];
@@ -1526,7 +1526,7 @@ extern "C" int sac_edge_get_gbar_mean(sac_edge_t *h, double *gbar_mean)
     const size_t nt = (size_t)h->cfg.n_tau;
     double n = (double)h->cfg.n_chains;
     if (h->comm && h->comm->merged) {                                // summed over all ranks' chains (edge_comm_merge)
-        HIP_TRY(hipMemcpy(gbar_mean, h->comm->dSum + h->off_gbar(), nt * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, gbar_mean, h->comm->dSum + h->off_gbar(), nt * sizeof(double), hipMemcpyDeviceToHost));
         n = h->comm->hTail[42];
     } else {
         hipLaunchKernelGGL(edge_gbar_sum_kernel, dim3(1), dim3(SAC_MAX_N_TAU), 0, h->stream, (const double *)h->dGbar,
@@ -1564,13 +1564,13 @@ extern "C" int sac_edge_get_move_log(sac_edge_t *h, sac_move_rec_t *out, int64_t
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     unsigned long long n = 0;
-    if (h->dLog) HIP_TRY(hipMemcpy(&n, h->dLogLen, sizeof(n), hipMemcpyDeviceToHost));
+    if (h->dLog) HIP_TRY(copy_sync(h->stream, &n, h->dLogLen, sizeof(n), hipMemcpyDeviceToHost));
     *n_recorded = (int64_t)n;
     long long m = (long long)n < h->log_cap ? (long long)n : h->log_cap;
     if (m > capacity) m = capacity;
     if (out && m > 0) {
         static_assert(sizeof(MoveRec) == sizeof(sac_move_rec_t), "move record layout");
-        HIP_TRY(hipMemcpy(out, h->dLog, (size_t)m * sizeof(MoveRec), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, out, h->dLog, (size_t)m * sizeof(MoveRec), hipMemcpyDeviceToHost));
     }
     return SAC_OK;
 }

@@ -1012,13 +1012,13 @@ extern "C" int sac_upload_problem(sac_handle_t *h, const double *K, const double
         if (!std::isfinite(G[j]) || !std::isfinite(sigma_inv[j]))
             return fail(SAC_E_INVALID, "sac_upload_problem: non-finite G or sigma_inv at tau index %zu", j);
     if ((size_t)h->ntp == nt) {
-        HIP_TRY(hipMemcpy(h->dK, K, ng * nt * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dK, K, ng * nt * sizeof(double), hipMemcpyHostToDevice));
     } else {
         HIP_TRY(hipMemcpy2D(h->dK, (size_t)h->ntp * sizeof(double), K, nt * sizeof(double),
                             nt * sizeof(double), ng, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMemcpy(h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
     h->problem = true;
     h->gbar_set = false;            // Gbar / chi2 of the old problem: sac_init_gbar (or sac_set_gbar) must follow
     return SAC_OK;
@@ -1035,8 +1035,8 @@ extern "C" int sac_upload_data(sac_handle_t *h, const double *G, const double *s
     for (size_t j = 0; j < nt; ++j)
         if (!std::isfinite(G[j]) || !std::isfinite(sigma_inv[j]))
             return fail(SAC_E_INVALID, "sac_upload_data: non-finite G or sigma_inv at tau index %zu", j);
-    HIP_TRY(hipMemcpy(h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dG, G, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dSinv, sigma_inv, nt * sizeof(double), hipMemcpyHostToDevice));
     h->problem = true;
     h->gbar_set = false;
     return SAC_OK;
@@ -1059,8 +1059,8 @@ extern "C" int sac_build_table(sac_handle_t *h, int32_t which, const sac_table_s
     double *d_tau = nullptr, *d_U = nullptr;
     HIP_TRY(hipMalloc(&d_tau, nt * sizeof(double)));
     if (hipMalloc(&d_U, nt * nt * sizeof(double)) != hipSuccess) { (void)hipFree(d_tau); return fail(SAC_E_HIP, "sac_build_table: out of device memory"); }
-    hipError_t e = hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice);
+    hipError_t e = copy_sync(h->stream, d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = copy_sync(h->stream, d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         TableSpec sp;
         sp.kernel_type = spec->kernel_type; sp.n_tau = (int)nt; sp.mirror = spec->mirror; sp.negate = spec->negate;
@@ -1104,8 +1104,8 @@ extern "C" int sac_build_table_noalloc(sac_handle_t *h, int32_t which, const sac
     // held from the first copy into the array to the end of the kernel that reads it: two host threads building tables
     // on one GPU (through any handles) take turns instead of overwriting each other's tau / U
     std::lock_guard<std::mutex> scratch_user(g_scratch_use[h->cfg.device]);
-    HIP_TRY(hipMemcpy(d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, d_tau, tau, nt * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, d_U, U, nt * nt * sizeof(double), hipMemcpyHostToDevice));
     TableSpec sp;
     sp.kernel_type = spec->kernel_type; sp.n_tau = (int)nt; sp.mirror = spec->mirror; sp.negate = spec->negate;
     sp.i_first = spec->i_first; sp.offset = spec->offset; sp.d_omega = spec->d_omega; sp.beta = spec->beta;
@@ -1161,7 +1161,7 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
         std::vector<uint32_t> all((size_t)count * (size_t)h->wi_stride);
         for (int c = 0; c < count; ++c)
             std::memcpy(all.data() + (size_t)c * h->wi_stride, rel.data(), (size_t)h->wi_stride * sizeof(uint32_t));
-        HIP_TRY(hipMemcpy(h->dWi + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(uint32_t),
+        HIP_TRY(copy_sync(h->stream, h->dWi + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(uint32_t),
                           hipMemcpyHostToDevice));
         h->state_set = true;
         h->gbar_set = false;        // the kernels never rebuild Gbar from the positions (free:876 assigns a dead local)
@@ -1177,7 +1177,7 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
         std::vector<double> all((size_t)count * (size_t)h->wi_stride);
         for (int c = 0; c < count; ++c)
             std::memcpy(all.data() + (size_t)c * h->wi_stride, pad.data(), (size_t)h->wi_stride * sizeof(double));
-        HIP_TRY(hipMemcpy(h->dA + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(double),
+        HIP_TRY(copy_sync(h->stream, h->dA + (size_t)first * h->wi_stride, all.data(), all.size() * sizeof(double),
                           hipMemcpyHostToDevice));
         if (chain == -1 || h->cfg.n_chains == 1) {
             h->uniform_A = uni;
@@ -1189,16 +1189,16 @@ extern "C" int sac_set_state(sac_handle_t *h, int32_t chain, const int64_t *wi, 
     }
     if (windows && h->peak) {
         std::vector<PeakScalars> sc((size_t)count);
-        HIP_TRY(hipMemcpy(sc.data(), h->dPsc + first, (size_t)count * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, sc.data(), h->dPsc + first, (size_t)count * sizeof(PeakScalars), hipMemcpyDeviceToHost));
         for (auto &s : sc)
             for (int k = 0; k < 11; ++k) s.windows[k] = windows[k];
-        HIP_TRY(hipMemcpy(h->dPsc + first, sc.data(), (size_t)count * sizeof(PeakScalars), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dPsc + first, sc.data(), (size_t)count * sizeof(PeakScalars), hipMemcpyHostToDevice));
     } else if (windows) {
         std::vector<ChainScalars> sc((size_t)count);
-        HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, (size_t)count * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, sc.data(), h->dSc + first, (size_t)count * sizeof(ChainScalars), hipMemcpyDeviceToHost));
         for (auto &s : sc)
             for (int k = 0; k < 4; ++k) s.windows[k] = windows[k];
-        HIP_TRY(hipMemcpy(h->dSc + first, sc.data(), (size_t)count * sizeof(ChainScalars), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dSc + first, sc.data(), (size_t)count * sizeof(ChainScalars), hipMemcpyHostToDevice));
     }
     return SAC_OK;
 }
@@ -1214,19 +1214,19 @@ extern "C" int sac_get_state(sac_handle_t *h, int32_t chain, int64_t *wi, double
     const int n = h->n_state;
     if (wi) {
         std::vector<uint32_t> rel((size_t)n);
-        HIP_TRY(hipMemcpy(rel.data(), h->dWi + (size_t)chain * h->wi_stride, (size_t)n * sizeof(uint32_t),
+        HIP_TRY(copy_sync(h->stream, rel.data(), h->dWi + (size_t)chain * h->wi_stride, (size_t)n * sizeof(uint32_t),
                           hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) wi[i] = (int64_t)rel[i] + h->pos_offset;
     }
     if (A)
-        HIP_TRY(hipMemcpy(A, h->dA + (size_t)chain * h->wi_stride, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, A, h->dA + (size_t)chain * h->wi_stride, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (windows && h->peak) {
         PeakScalars s;
-        HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
         for (int k = 0; k < 11; ++k) windows[k] = s.windows[k];
     } else if (windows) {
         ChainScalars s;
-        HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
         for (int k = 0; k < 4; ++k) windows[k] = s.windows[k];
     }
     return SAC_OK;
@@ -1294,17 +1294,17 @@ extern "C" int sac_get_gbar(sac_handle_t *h, int32_t chain, double *gbar, double
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (gbar)
-        HIP_TRY(hipMemcpy(gbar, h->dGbar + (size_t)chain * SAC_MAX_N_TAU, (size_t)h->cfg.n_tau * sizeof(double),
+        HIP_TRY(copy_sync(h->stream, gbar, h->dGbar + (size_t)chain * SAC_MAX_N_TAU, (size_t)h->cfg.n_tau * sizeof(double),
                           hipMemcpyDeviceToHost));
     if (h->peak) {
         PeakScalars s;
-        HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
         if (chi2) *chi2 = s.chi2;
         if (chi2_min) *chi2_min = s.chi2_min;
         return SAC_OK;
     }
     ChainScalars s;
-    HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, &s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
     if (chi2) *chi2 = s.chi2;
     if (chi2_min) *chi2_min = s.chi2_min;
     return SAC_OK;
@@ -1319,7 +1319,7 @@ extern "C" int sac_get_gbar_mean(sac_handle_t *h, double *gbar_mean)
     double n = (double)h->cfg.n_chains;
     if (h->comm && h->comm->merged && h->last_stage == 2) {           // summed over all ranks' chains (comm_merge)
         const size_t n_hist = (size_t)h->cfg.n_grid * (size_t)h->hist_arrays;
-        HIP_TRY(hipMemcpy(gbar_mean, h->comm->dSum + n_hist, nt * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, gbar_mean, h->comm->dSum + n_hist, nt * sizeof(double), hipMemcpyDeviceToHost));
         n = h->comm->hTail[h->peak ? 44 : 18];
     } else {
         hipLaunchKernelGGL(gbar_sum_kernel, dim3(1), dim3(SAC_MAX_N_TAU), 0, h->stream, (const double *)h->dGbar, h->cfg.n_chains,
@@ -1344,14 +1344,14 @@ extern "C" int sac_set_gbar(sac_handle_t *h, int32_t chain, const double *gbar, 
     std::vector<double> pad(SAC_MAX_N_TAU, 0.0);
     std::memcpy(pad.data(), gbar, (size_t)h->cfg.n_tau * sizeof(double));
     std::vector<ChainScalars> sc((size_t)count);
-    HIP_TRY(hipMemcpy(sc.data(), h->dSc + first, (size_t)count * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, sc.data(), h->dSc + first, (size_t)count * sizeof(ChainScalars), hipMemcpyDeviceToHost));
     for (int c = 0; c < count; ++c) {
-        HIP_TRY(hipMemcpy(h->dGbar + (size_t)(first + c) * SAC_MAX_N_TAU, pad.data(),
+        HIP_TRY(copy_sync(h->stream, h->dGbar + (size_t)(first + c) * SAC_MAX_N_TAU, pad.data(),
                           SAC_MAX_N_TAU * sizeof(double), hipMemcpyHostToDevice));
         sc[c].chi2 = chi2;
         sc[c].chi2_min = chi2_min;
     }
-    HIP_TRY(hipMemcpy(h->dSc + first, sc.data(), (size_t)count * sizeof(ChainScalars), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dSc + first, sc.data(), (size_t)count * sizeof(ChainScalars), hipMemcpyHostToDevice));
     h->gbar_set = true;
     return SAC_OK;
 }
@@ -1661,7 +1661,7 @@ extern "C" int sac_upload_problem_peak(sac_handle_t *h, const double *Kp, const 
     if (Kn) {
         const size_t nt = (size_t)h->cfg.n_tau, ng = (size_t)h->cfg.n_grid;
         if ((size_t)h->ntp == nt) {
-            HIP_TRY(hipMemcpy(h->dKn, Kn, ng * nt * sizeof(double), hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(h->stream, h->dKn, Kn, ng * nt * sizeof(double), hipMemcpyHostToDevice));
         } else {
             HIP_TRY(hipMemcpy2D(h->dKn, (size_t)h->ntp * sizeof(double), Kn, nt * sizeof(double),
                                 nt * sizeof(double), ng, hipMemcpyHostToDevice));
@@ -1815,7 +1815,7 @@ static int peak_chain_stats(sac_handle *h, int32_t chain, double *out6, double *
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     PeakScalars s;
-    HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, &s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
     const double steps = (double)h->last_steps;
     if (out6) {
         out6[0] = (h->last_stage == 2) ? s.sum_chi2 / steps : 0.0;
@@ -1839,7 +1839,7 @@ extern "C" int sac_get_bounds(sac_handle_t *h, int32_t chain, double *out4)
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     PeakScalars s;
-    HIP_TRY(hipMemcpy(&s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, &s, h->dPsc + chain, sizeof(s), hipMemcpyDeviceToHost));
     for (int k = 0; k < 4; ++k) out4[k] = (double)s.bounds[k];
     return SAC_OK;
 }
@@ -1870,7 +1870,7 @@ extern "C" int sac_get_peak_stats(sac_handle_t *h, sac_peak_stats_t *out)
     }
     const int nc = h->cfg.n_chains;
     std::vector<PeakScalars> sc((size_t)nc);
-    HIP_TRY(hipMemcpy(sc.data(), h->dPsc, (size_t)nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, sc.data(), h->dPsc, (size_t)nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
     hipLaunchKernelGGL(peak_weights_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, h->stream,
                        (const double *)h->dA, h->wi_stride, nc, h->cfg.n_peak, h->cfg.n_omega, h->dWeights);
     HIP_TRY(hipGetLastError());
@@ -1920,7 +1920,7 @@ extern "C" int sac_get_histogram_peak(sac_handle_t *h, int32_t which, double *ou
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ng = (size_t)h->cfg.n_grid;
     if (h->comm && h->comm->merged && h->last_stage == 2) {           // summed over all ranks' chains (comm_merge)
-        HIP_TRY(hipMemcpy(out, h->comm->dSum + (size_t)which * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, out, h->comm->dSum + (size_t)which * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
         const double n = h->comm->hTail[44], div = h->binned ? 1.0 : (double)h->last_steps;
         for (size_t i = 0; i < ng; ++i) out[i] = out[i] / div / n;
         return SAC_OK;
@@ -1928,7 +1928,7 @@ extern "C" int sac_get_histogram_peak(sac_handle_t *h, int32_t which, double *ou
     std::vector<double> tmp(ng);
     std::fill(out, out + ng, 0.0);
     for (int c = 0; c < h->hist_copies; ++c) {
-        HIP_TRY(hipMemcpy(tmp.data(), h->dHist + ((size_t)c * 4 + (size_t)which) * ng, ng * sizeof(double),
+        HIP_TRY(copy_sync(h->stream, tmp.data(), h->dHist + ((size_t)c * 4 + (size_t)which) * ng, ng * sizeof(double),
                           hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ng; ++i) out[i] = (c == 0) ? tmp[i] : out[i] + tmp[i];
     }
@@ -1991,7 +1991,7 @@ extern "C" int sac_get_stats(sac_handle_t *h, sac_stats_t *out)
     }
     const int nc = h->cfg.n_chains;
     std::vector<ChainScalars> sc((size_t)nc);
-    HIP_TRY(hipMemcpy(sc.data(), h->dSc, (size_t)nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, sc.data(), h->dSc, (size_t)nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof(*out));
     const double steps = (double)h->last_steps;
     double s_chi2 = 0.0, cmm = 0.0, ar[6] = {0, 0, 0, 0, 0, 0}, win[4] = {0, 0, 0, 0};
@@ -2036,7 +2036,7 @@ extern "C" int sac_get_chain_stats(sac_handle_t *h, int32_t chain, double *out6,
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     ChainScalars s;
-    HIP_TRY(hipMemcpy(&s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, &s, h->dSc + chain, sizeof(s), hipMemcpyDeviceToHost));
     const double steps = (double)h->last_steps;
     if (out6) {
         out6[0] = (h->last_stage == 2) ? s.sum_chi2 / steps : 0.0;
@@ -2092,7 +2092,7 @@ extern "C" int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sa
     dC = b_dC.as<std::remove_pointer_t<decltype(dC)>>();
     HIP_TRY(b_dAcc.alloc((size_t)n * sizeof(int)));
     dAcc = b_dAcc.as<std::remove_pointer_t<decltype(dAcc)>>();
-    HIP_TRY(hipMemcpy(dP, rel.data(), (size_t)n * sizeof(ReplayProp), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, dP, rel.data(), (size_t)n * sizeof(ReplayProp), hipMemcpyHostToDevice));
     FreeParams p;
     fill_params(h, p);
     p.inv2theta = 1.0 / (2.0 * theta);
@@ -2100,8 +2100,8 @@ extern "C" int sac_replay(sac_handle_t *h, int32_t chain, double theta, const sa
     else hipLaunchKernelGGL(replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, p, (int)chain, dP, (long long)n, dC, dAcc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (chi2_new) HIP_TRY(copy_sync(h->stream, chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(copy_sync(h->stream, accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return stage_end(h, 0, 0);
 }
 
@@ -2145,7 +2145,7 @@ extern "C" int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, con
     dC = b_dC.as<std::remove_pointer_t<decltype(dC)>>();
     HIP_TRY(b_dAcc.alloc((size_t)n * sizeof(int)));
     dAcc = b_dAcc.as<std::remove_pointer_t<decltype(dAcc)>>();
-    HIP_TRY(hipMemcpy(dP, props, (size_t)n * sizeof(PeakReplayProp), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(h->stream, dP, props, (size_t)n * sizeof(PeakReplayProp), hipMemcpyHostToDevice));
     PeakParams pp;
     fill_peak_params(h, pp);
     pp.f.inv2theta = 1.0 / (2.0 * theta);
@@ -2153,8 +2153,8 @@ extern "C" int sac_replay_peak(sac_handle_t *h, int32_t chain, double theta, con
     else hipLaunchKernelGGL(peak_replay_kernel<2>, dim3(1), dim3(64), 0, h->stream, pp, (int)chain, dP, (long long)n, dC, dAcc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (chi2_new) HIP_TRY(hipMemcpy(chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (accepted) HIP_TRY(hipMemcpy(accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (chi2_new) HIP_TRY(copy_sync(h->stream, chi2_new, dC, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (accepted) HIP_TRY(copy_sync(h->stream, accepted, dAcc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return stage_end(h, 0, 0);
 }
 
@@ -2185,14 +2185,14 @@ extern "C" int sac_get_chain_chi2(sac_handle_t *h, double *chi2, double *chi2_mi
     const size_t nc = (size_t)h->cfg.n_chains;
     if (h->peak) {
         std::vector<PeakScalars> v(nc);
-        HIP_TRY(hipMemcpy(v.data(), h->dPsc, nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, v.data(), h->dPsc, nc * sizeof(PeakScalars), hipMemcpyDeviceToHost));
         for (size_t c = 0; c < nc; ++c) {
             if (chi2) chi2[c] = v[c].chi2;
             if (chi2_min) chi2_min[c] = v[c].chi2_min;
         }
     } else {
         std::vector<ChainScalars> v(nc);
-        HIP_TRY(hipMemcpy(v.data(), h->dSc, nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, v.data(), h->dSc, nc * sizeof(ChainScalars), hipMemcpyDeviceToHost));
         for (size_t c = 0; c < nc; ++c) {
             if (chi2) chi2[c] = v[c].chi2;
             if (chi2_min) chi2_min[c] = v[c].chi2_min;
@@ -2214,33 +2214,33 @@ extern "C" int sac_copy_chain(sac_handle_t *h, int32_t src, int32_t dst)
     drop_merged(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ws = (size_t)h->wi_stride;
-    HIP_TRY(hipMemcpy(h->dWi + dst * ws, h->dWi + src * ws, ws * sizeof(uint32_t), hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(h->dA + dst * ws, h->dA + src * ws, ws * sizeof(double), hipMemcpyDeviceToDevice));
-    HIP_TRY(hipMemcpy(h->dGbar + (size_t)dst * SAC_MAX_N_TAU, h->dGbar + (size_t)src * SAC_MAX_N_TAU,
+    HIP_TRY(copy_sync(h->stream, h->dWi + dst * ws, h->dWi + src * ws, ws * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dA + dst * ws, h->dA + src * ws, ws * sizeof(double), hipMemcpyDeviceToDevice));
+    HIP_TRY(copy_sync(h->stream, h->dGbar + (size_t)dst * SAC_MAX_N_TAU, h->dGbar + (size_t)src * SAC_MAX_N_TAU,
                       SAC_MAX_N_TAU * sizeof(double), hipMemcpyDeviceToDevice));
     // scalars: everything but the destination's own sweep counter (its Philox stream) and counters
     if (h->peak) {
         PeakScalars a, b;
-        HIP_TRY(hipMemcpy(&a, h->dPsc + src, sizeof(a), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&b, h->dPsc + dst, sizeof(b), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &a, h->dPsc + src, sizeof(a), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &b, h->dPsc + dst, sizeof(b), hipMemcpyDeviceToHost));
         const unsigned long long sweep = b.sweep;
         unsigned long long cnt[5];
         std::memcpy(cnt, b.counters, sizeof(cnt));
         b = a;
         b.sweep = sweep;
         std::memcpy(b.counters, cnt, sizeof(cnt));
-        HIP_TRY(hipMemcpy(h->dPsc + dst, &b, sizeof(b), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dPsc + dst, &b, sizeof(b), hipMemcpyHostToDevice));
     } else {
         ChainScalars a, b;
-        HIP_TRY(hipMemcpy(&a, h->dSc + src, sizeof(a), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&b, h->dSc + dst, sizeof(b), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &a, h->dSc + src, sizeof(a), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, &b, h->dSc + dst, sizeof(b), hipMemcpyDeviceToHost));
         const unsigned long long sweep = b.sweep;
         unsigned long long cnt[5];
         std::memcpy(cnt, b.counters, sizeof(cnt));
         b = a;
         b.sweep = sweep;
         std::memcpy(b.counters, cnt, sizeof(cnt));
-        HIP_TRY(hipMemcpy(h->dSc + dst, &b, sizeof(b), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(h->stream, h->dSc + dst, &b, sizeof(b), hipMemcpyHostToDevice));
     }
     return SAC_OK;
 }
@@ -2255,15 +2255,15 @@ extern "C" int sac_get_histogram(sac_handle_t *h, double *out)
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t ng = (size_t)h->cfg.n_grid;
     if (h->comm && h->comm->merged) {                                // summed over all ranks' chains (comm_merge)
-        HIP_TRY(hipMemcpy(out, h->comm->dSum, ng * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, out, h->comm->dSum, ng * sizeof(double), hipMemcpyDeviceToHost));
         const double steps = (double)h->last_steps, n = h->comm->hTail[18];
         for (size_t i = 0; i < ng; ++i) out[i] = out[i] / steps / n;
         return SAC_OK;
     }
     std::vector<double> tmp(ng);
-    HIP_TRY(hipMemcpy(out, h->dHist, ng * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, out, h->dHist, ng * sizeof(double), hipMemcpyDeviceToHost));
     for (int c = 1; c < h->hist_copies; ++c) {
-        HIP_TRY(hipMemcpy(tmp.data(), h->dHist + (size_t)c * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(h->stream, tmp.data(), h->dHist + (size_t)c * ng, ng * sizeof(double), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < ng; ++i) out[i] = out[i] + tmp[i];
     }
     const double steps = (double)h->last_steps, nc = (double)h->cfg.n_chains;
@@ -2361,12 +2361,12 @@ extern "C" int sac_get_move_log(sac_handle_t *h, sac_move_rec_t *out, int64_t ca
     if ((rc = use_device(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     unsigned long long n = 0;
-    HIP_TRY(hipMemcpy(&n, h->dLogLen, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(h->stream, &n, h->dLogLen, sizeof(n), hipMemcpyDeviceToHost));
     *n_recorded = (int64_t)n;
     int64_t m = (int64_t)n;
     if (m > h->log_cap) m = h->log_cap;
     if (m > capacity) m = capacity;
     static_assert(sizeof(MoveRec) == sizeof(sac_move_rec_t), "move record layout");
-    if (out && m > 0) HIP_TRY(hipMemcpy(out, h->dLog, (size_t)m * sizeof(MoveRec), hipMemcpyDeviceToHost));
+    if (out && m > 0) HIP_TRY(copy_sync(h->stream, out, h->dLog, (size_t)m * sizeof(MoveRec), hipMemcpyDeviceToHost));
     return SAC_OK;
 }

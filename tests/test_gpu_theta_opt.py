@@ -5,7 +5,6 @@ added, and so would Theta_opt.  The drivers' default (chi2_min_mode="chain_mean"
 the chains of each chain's own chi2_min, and for the edge rule the median of the chains' own first passages.  Each test runs the
 reference's ladder and stop rules on few and on many chains (different seeds, fewer sweeps per stage than the reference to keep
 the suite short) and requires the same ladder point or a close neighbour, and the reference run's own Theta_opt nearby."""
-import multiprocessing as mp
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -20,15 +19,11 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _together(*jobs, processes=False):
-    """Runs side by side: they are independent handles, every one leaves most of the GPU idle (at most 64 wavefronts) and its
-    wall-clock is the latency of its chains, so together they take about the time of the longest.  Host threads for the free and
-    peak drivers (handles are per driver task; the library's error state is thread-local); separate processes for the edge
-    driver, whose stage calls copy their scalar blocks on the null stream, which waits for every other handle of a process."""
-    if processes:
-        with mp.get_context("spawn").Pool(len(jobs)) as pool:
-            results = [pool.apply_async(job[0], job[1:]) for job in jobs]
-            return [r.get(timeout=560) for r in results]
+def _together(*jobs):
+    """Runs side by side, one host thread each: they are independent handles on their own streams, every one leaves most of the
+    GPU idle (at most 64 wavefronts) and its wall-clock is the latency of its chains, so together they take about the time of
+    the longest (handles are per driver task; the library's error state is thread-local and its copies are ordered on the
+    handle's own stream, so one run never waits for another's kernels)."""
     with ThreadPoolExecutor(len(jobs)) as ex:
         futures = [ex.submit(*job) for job in jobs]
         return [f.result() for f in futures]
@@ -110,7 +105,7 @@ def test_edge_theta_opt_is_the_median_first_passage_at_any_chain_count(tmp_path)
     range of the 64 chains of the full run spans a factor > 3 in Theta; the reference's own run sits at its 12th percentile).  The
     many-chain rule stops when half the chains have passed: its Theta_opt is the median of that distribution, whatever the count."""
     (few, fp_few, f), (many, fp_many, _), (one, fp_one, _) = _together(
-        (_edge_theta, tmp_path, 16, 9), (_edge_theta, tmp_path, 64, 3), (_edge_theta, tmp_path, 1, 5), processes=True)
+        (_edge_theta, tmp_path, 16, 9), (_edge_theta, tmp_path, 64, 3), (_edge_theta, tmp_path, 1, 5))
     print("edge theta_opt: 16 chains", few, "64 chains", many, "passages", np.sort(fp_few[fp_few > 0]), np.sort(fp_many[fp_many > 0]))
     # The first-passage distribution is broad and flat around its middle (stages 6 ... 21 on this ladder), so the comparison is made
     # in quantiles, not in ladder stages: by the stage at which the 16-chain run stopped, between a quarter and three quarters of
