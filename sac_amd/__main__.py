@@ -27,6 +27,8 @@ def main(argv=None):
     ap.add_argument("--chains", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--side-by-side", type=int, default=1, help="scan / cv-all: units a rank runs at a time on its GPU, one host "
+                    "thread each (complete runs with few chains leave the GPU empty; 3 or 4 per process is what its queues carry)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
                                                        "(nccl = RCCL; gloo for rehearsals on shared GPUs)")
     a = ap.parse_args(argv)
@@ -82,7 +84,7 @@ def main(argv=None):
             # scan points are whole runs (minutes each) dealt round-robin: the ranks reach the final gather far apart
             dist.init_process_group(a.backend, timeout=GATHER_TIMEOUT,
                                     **({"device_id": torch.device("cuda", kw["device"])} if a.backend == "nccl" else {}))
-        results = run_scan_partition(units, rank, world, **kw)
+        results = run_scan_partition(units, rank, world, side_by_side=a.side_by_side, **kw)
         if rank == 0:
             for u in units:
                 print(dict(u[1]), results[u])
@@ -105,7 +107,7 @@ def main(argv=None):
             ap.error("cv-all needs: REP_FIRST REP_LAST [free,peak,edge]")
         params = tuple(a.args[2].split(",")) if len(a.args) > 2 else ("free", "peak", "edge")
         units = cv_units(range(int(a.args[0]), int(a.args[1]) + 1), params)
-        folders = run_cv_partition(units, rank, world, **kw)
+        folders = run_cv_partition(units, rank, world, side_by_side=a.side_by_side, **kw)
         if rank == 0:
             for u in units:
                 print(u, folders[u])

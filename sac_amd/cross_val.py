@@ -236,13 +236,22 @@ def gather_objects(obj, world):
     return out
 
 
-def run_partition(units, rank, world, runner, gather=None, **kw):
+def run_partition(units, rank, world, runner, gather=None, side_by_side=1, **kw):
     """Deals `units` round-robin to the ranks, runs this rank's share with runner(unit, **kw) and returns, on every
     rank, {unit: result} for all units.  gather(obj) -> list of every rank's obj (default: gather_objects, a gloo
-    all_gather_object with a long timeout, when world > 1).  Shared by the cross-validation units and the scans (scan.py)."""
-    mine = {}
-    for unit in partition_units(units, rank, world):
-        mine[unit] = runner(unit, **kw)
+    all_gather_object with a long timeout, when world > 1).  Shared by the cross-validation units and the scans (scan.py).
+    side_by_side > 1: that many of the rank's units at a time, one host thread each.  A unit is a complete run with few
+    chains -- a latency-bound sequence of small launches that leaves the GPU empty -- and handles are independent of each
+    other (own stream, copies ordered on it), so a rank's units overlap on its GPU (three to four per
+    process is what the hardware queues of one process carry).  The results do not depend on it."""
+    share = partition_units(units, rank, world)
+    if side_by_side > 1 and len(share) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(int(side_by_side)) as ex:
+            futures = [(unit, ex.submit(runner, unit, **kw)) for unit in share]
+            mine = {unit: f.result() for unit, f in futures}
+    else:
+        mine = {unit: runner(unit, **kw) for unit in share}
     if world == 1:
         return mine
     if gather is None:
@@ -257,14 +266,14 @@ def run_partition(units, rank, world, runner, gather=None, **kw):
     return merged
 
 
-def run_cv_partition(units, rank=0, world=1, runner=None, gather=None, **kw):
+def run_cv_partition(units, rank=0, world=1, runner=None, gather=None, side_by_side=1, **kw):
     """Runs this rank's share of `units` and returns, on every rank, {unit: output folder} for all units.
     runner(unit, **kw) -> output folder; default = free_cv / peak_cv / edge_cv on this rank's GPU."""
     if runner is None:
         def runner(unit, **k):
             prm, rep, ab = unit
             return {"free": free_cv, "peak": peak_cv, "edge": edge_cv}[prm](rep, ab, **k).output_folder
-    return run_partition(units, rank, world, runner, gather, **kw)
+    return run_partition(units, rank, world, runner, gather, side_by_side=side_by_side, **kw)
 
 
 def cv_curves(folders, tin_folder, params=("free", "peak", "edge")):

@@ -65,10 +65,11 @@ def _run_point(unit, in_file=None, **kw):
     return out
 
 
-def run_scan_partition(units, rank=0, world=1, runner=None, gather=None, **kw):
+def run_scan_partition(units, rank=0, world=1, runner=None, gather=None, side_by_side=1, **kw):
     """Runs this rank's scan points and returns, on every rank, {unit: result} for all points.
-    runner(unit, **kw) -> result (default: the program's complete run at that parameter point on this rank's GPU)."""
-    return run_partition(units, rank, world, runner or _run_point, gather, **kw)
+    runner(unit, **kw) -> result (default: the program's complete run at that parameter point on this rank's GPU).
+    side_by_side: points a rank runs at a time on its GPU (cross_val.run_partition)."""
+    return run_partition(units, rank, world, runner or _run_point, gather, side_by_side=side_by_side, **kw)
 
 
 def best_point(results, key="chi2_avg"):

@@ -239,3 +239,39 @@ def test_theta_scan_points_follow_the_reference_ladder():
         scan_units("peak", "p", [0.1])
     u = scan_units("peak", "A_0", [0.5, 0.6], N_p=1)
     assert [dict(x[1]) for x in u] == [{"A_0": 0.5, "N_p": 1}, {"A_0": 0.6, "N_p": 1}]
+
+
+def test_units_of_a_rank_side_by_side():
+    """side_by_side: a rank's units run in host threads, several at a time; same {unit: result} map, really overlapped."""
+    import threading
+    import time
+    from sac_amd.scan import run_scan_partition, scan_units, scan_values
+    units = scan_units("edge", "p", scan_values("0.3", "0.1", 6), A_c=0.0, A_r=0.5)
+    live, peak, lock = [0], [0], threading.Lock()
+
+    def runner(unit, **kw):
+        with lock:
+            live[0] += 1
+            peak[0] = max(peak[0], live[0])
+        time.sleep(0.3)
+        with lock:
+            live[0] -= 1
+        return dict(chi2_avg=dict(unit[1])["p"], thread=threading.get_ident())
+
+    t0 = time.time()
+    seq = run_scan_partition(units, runner=runner)
+    t_seq, peak_seq = time.time() - t0, peak[0]
+    peak[0] = 0
+    t0 = time.time()
+    par = run_scan_partition(units, runner=runner, side_by_side=3)
+    t_par = time.time() - t0
+    assert peak_seq == 1 and peak[0] == 3
+    assert list(par) == list(seq) == units and [r["chi2_avg"] for r in par.values()] == [r["chi2_avg"] for r in seq.values()]
+    assert t_par < 0.75 * t_seq
+
+    def failing(unit, **kw):
+        if dict(unit[1])["p"] > 0.55:
+            raise RuntimeError("this point failed")
+        return dict(chi2_avg=1.0)
+    with pytest.raises(RuntimeError, match="this point failed"):
+        run_scan_partition(units, runner=failing, side_by_side=3)
